@@ -1,0 +1,392 @@
+/*
+ * ldpc_oracle.c -- CPU restatement of the reference's LDPC decode hot path.
+ * TEST INFRASTRUCTURE ONLY -- see ldpc_oracle.h for the rules and the parity
+ * status (pinned through tests/golden/ against the reference's kernel source).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared ldpc_oracle.c -lm
+ */
+#include "ldpc_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../myldpccppapi_amd/csrc/wimax_seeds.h" /* data only */
+
+/* ------------------------------------------------------------------ seeds */
+
+int oracle_seed_rows(int rate)
+{
+    return (rate >= 0 && rate < WIMAX_NUM_RATES) ? wimax_seed_rows[rate] : -1;
+}
+
+const signed char *oracle_seed(int rate)
+{
+    return (rate >= 0 && rate < WIMAX_NUM_RATES) ? wimax_seed_table[rate] : NULL;
+}
+
+int64_t oracle_wimax_nnz(int rate)
+{
+    int mb = oracle_seed_rows(rate);
+    if (mb < 0) return -1;
+    const signed char *s = oracle_seed(rate);
+    int64_t n = 0;
+    for (int i = 0; i < mb * WIMAX_NB; ++i) n += (s[i] >= 0);
+    return n;
+}
+
+/* MyLdpc.cpp:52-109.  z = N / 24 (:55); shift = p*z/96, or p % z for rate
+ * 2/3A (:89-94); block entry at (r, c) iff (z + c - r) % z == shift (:97).
+ * Row-major order = for each row, block columns ascending. */
+int64_t oracle_wimax_edges(int rate, int32_t N, int32_t *rows, int32_t *cols)
+{
+    int mb = oracle_seed_rows(rate);
+    if (mb < 0 || N <= 0) return -1;
+    const signed char *s = oracle_seed(rate);
+    const int z = N / WIMAX_NB;
+    int64_t e = 0;
+    for (int sr = 0; sr < mb; ++sr)
+        for (int pr = 0; pr < z; ++pr)
+            for (int sc = 0; sc < WIMAX_NB; ++sc) {
+                int p = s[sr * WIMAX_NB + sc];
+                if (p < 0) continue;
+                p = (rate != 1) ? p * z / WIMAX_Z0 : p % z;
+                rows[e] = sr * z + pr;
+                cols[e] = sc * z + (pr + p) % z;
+                ++e;
+            }
+    return e;
+}
+
+/* -------------------------------------------------------------- adjacency */
+
+/* MyLdpc.cpp:171-222.  The reference threads -1-terminated linked lists through
+ * the edges; both lists are appended in edge order, so walking a row list or a
+ * column list visits edges in ascending edge id.  CSR/CSC arrays with the same
+ * visiting order are equivalent. */
+int oracle_build_adjacency(int32_t M, int32_t N, int64_t E,
+                           const int32_t *rows, const int32_t *cols,
+                           int32_t *row_ptr, int32_t *col_ptr, int32_t *col_edge)
+{
+    for (int64_t e = 0; e < E; ++e) {
+        if (rows[e] < 0 || rows[e] >= M || cols[e] < 0 || cols[e] >= N) return -1;
+        if (e && (rows[e] < rows[e - 1] ||
+                  (rows[e] == rows[e - 1] && cols[e] <= cols[e - 1])))
+            return -1;
+    }
+    memset(row_ptr, 0, sizeof(int32_t) * ((size_t)M + 1));
+    memset(col_ptr, 0, sizeof(int32_t) * ((size_t)N + 1));
+    for (int64_t e = 0; e < E; ++e) { ++row_ptr[rows[e] + 1]; ++col_ptr[cols[e] + 1]; }
+    for (int32_t m = 0; m < M; ++m) row_ptr[m + 1] += row_ptr[m];
+    for (int32_t n = 0; n < N; ++n) col_ptr[n + 1] += col_ptr[n];
+    int32_t *fill = (int32_t *)malloc(sizeof(int32_t) * (size_t)N);
+    if (!fill) return -2;
+    memcpy(fill, col_ptr, sizeof(int32_t) * (size_t)N);
+    for (int64_t e = 0; e < E; ++e) col_edge[fill[cols[e]]++] = (int32_t)e;
+    free(fill);
+    return 0;
+}
+
+/* ---------------------------------------------------------------- helpers */
+
+int64_t oracle_code_size(int64_t src_length, int32_t K)
+{
+    /* MyLdpc.cpp:628-631 */
+    return (src_length + (K / 8) - 1) / (K / 8);
+}
+
+static void pack_frame(const oracle_graph *g, const uint8_t *bits, int64_t frame,
+                       int pack_mode, uint8_t *out, int64_t out_bytes)
+{
+    const int32_t K = g->K;
+    if (!out) return;
+    if (pack_mode == 0) {
+        /* toChar, decodeCL.c:188-199: byte j of the frame lands at
+         * frame*K/8 + j (integer division of the product), j < K/8. */
+        const int64_t base = frame * (int64_t)K / 8;
+        for (int32_t j = 0; j < K / 8; ++j) {
+            uint8_t v = 0;
+            for (int b = 0; b < 8; ++b)
+                if (bits[j * 8 + b]) v |= (uint8_t)(1u << b);
+            if (base + j < out_bytes) out[base + j] = v;
+        }
+    } else {
+        /* decodeCPU, MyLdpc.cpp:765-774 (the reference also touches byte
+         * srcLength; we stop at out_bytes). */
+        for (int32_t i = 0; i < K; ++i)
+            if (bits[i]) {
+                const int64_t off = frame * (int64_t)K + i;
+                if (off / 8 < out_bytes) out[off / 8] |= (uint8_t)(1u << (off % 8));
+            }
+    }
+}
+
+/* checkResult, decodeCL.c:88-108 / MyLdpc.cpp:737-750: any row with odd parity. */
+static int syndrome_fails(const oracle_graph *g, const uint8_t *bits)
+{
+    for (int32_t m = 0; m < g->M; ++m) {
+        int r = 0;
+        for (int32_t p = g->row_ptr[m]; p < g->row_ptr[m + 1]; ++p)
+            if (bits[g->cols[p]]) r ^= 1;
+        if (r) return 1;
+    }
+    return 0;
+}
+
+static void tap_copy(float *dst, int64_t frame, int64_t n, const float *src)
+{
+    if (dst) memcpy(dst + frame * n, src, sizeof(float) * (size_t)n);
+}
+
+/* ------------------------------------------------------- min-sum flooding */
+
+int oracle_decode_ms(const oracle_graph *g, const float *y, int64_t frames,
+                     int max_iter, int pack_mode, uint8_t *out, int64_t out_bytes,
+                     int32_t *iters, uint8_t *hard_out, const oracle_taps *taps)
+{
+    const int64_t E = g->E;
+    const int32_t N = g->N;
+    float *lQ = (float *)malloc(sizeof(float) * (size_t)E);
+    float *lR = (float *)malloc(sizeof(float) * (size_t)E);
+    float *lPostP = (float *)malloc(sizeof(float) * (size_t)N);
+    uint8_t *src = (uint8_t *)calloc((size_t)N, 1);
+    if (!lQ || !lR || !lPostP || !src) return -2;
+
+    for (int64_t f = 0; f < frames; ++f) {
+        const float *yf = y + f * N;
+        int time = 0;
+        /* decodeInitMS, decodeCL.c:113-124 (MyLdpc.cpp:697-702 keeps the same
+         * value split into sign and magnitude) */
+        for (int64_t e = 0; e < E; ++e) lQ[e] = yf[g->cols[e]];
+        while (1) {
+            /* refreshRMS, decodeCL.c:126-147 / MyLdpc.cpp:705-721 */
+            for (int64_t e = 0; e < E; ++e) {
+                const int32_t row = g->rows[e];
+                int a = 0;
+                float b = 1000;
+                for (int32_t p = g->row_ptr[row]; p < g->row_ptr[row + 1]; ++p) {
+                    if (p == e) continue;
+                    if (lQ[p] < 0) a ^= 1;
+                    b = fminf(b, fabsf(lQ[p]));
+                }
+                lR[e] = a ? -b : b;
+            }
+            /* refreshPostPMS, decodeCL.c:149-171 / MyLdpc.cpp:723-735 */
+            for (int32_t n = 0; n < N; ++n) {
+                float tmp = yf[n];
+                for (int32_t p = g->col_ptr[n]; p < g->col_ptr[n + 1]; ++p)
+                    tmp += lR[g->col_edge[p]];
+                src[n] = (tmp > 0) ? 0 : 1;
+                lPostP[n] = tmp;
+            }
+            const int flag = syndrome_fails(g, src);
+            ++time;
+            if (taps && taps->iter == time) {
+                tap_copy(taps->r, f, E, lR);
+                tap_copy(taps->post, f, N, lPostP);
+            }
+            if (!flag) break;              /* MyLdpc.cpp:751-755, 824-833 */
+            if (time == max_iter) break;
+            /* refreshQMS, decodeCL.c:175-186 / MyLdpc.cpp:757-762 */
+            for (int64_t e = 0; e < E; ++e) lQ[e] = lPostP[g->cols[e]] - lR[e];
+            if (taps && taps->iter == time) tap_copy(taps->q, f, E, lQ);
+        }
+        if (iters) iters[f] = time;
+        if (hard_out) memcpy(hard_out + f * N, src, (size_t)N);
+        pack_frame(g, src, f, pack_mode, out, out_bytes);
+    }
+    free(lQ); free(lR); free(lPostP); free(src);
+    return 0;
+}
+
+/* ---------------------------------------------------- sum-product flooding */
+
+int oracle_decode_sp(const oracle_graph *g, const float *y, int64_t frames,
+                     int max_iter, float llr_scale, int pack_mode, uint8_t *out,
+                     int64_t out_bytes, int32_t *iters, uint8_t *hard_out,
+                     const oracle_taps *taps)
+{
+    const int64_t E = g->E;
+    const int32_t N = g->N;
+    float *q0 = (float *)malloc(sizeof(float) * (size_t)E);
+    float *q1 = (float *)malloc(sizeof(float) * (size_t)E);
+    float *r0 = (float *)malloc(sizeof(float) * (size_t)E);
+    float *r1 = (float *)malloc(sizeof(float) * (size_t)E);
+    float *p0 = (float *)malloc(sizeof(float) * (size_t)N);
+    float *p1 = (float *)malloc(sizeof(float) * (size_t)N);
+    uint8_t *src = (uint8_t *)malloc((size_t)N);
+    if (!q0 || !q1 || !r0 || !r1 || !p0 || !p1 || !src) return -2;
+
+    for (int64_t f = 0; f < frames; ++f) {
+        const float *yf = y + f * N;
+        int time = 0;
+        /* the reference never clears memSrcBool (MyLdpc.cpp:278-279); the
+         * harness and the product both start from all-zero bits */
+        memset(src, 0, (size_t)N);
+        /* decodeInit, decodeCL.c:3-22 */
+        for (int32_t n = 0; n < N; ++n) {
+            const float tmp = expf(llr_scale * yf[n]);
+            p0[n] = tmp / (1 + tmp);
+            p1[n] = 1 / (1 + tmp);
+        }
+        for (int64_t e = 0; e < E; ++e) {
+            const float tmp = expf(llr_scale * yf[g->cols[e]]);
+            q0[e] = tmp / (1 + tmp);
+            q1[e] = 1 / (1 + tmp);
+        }
+        while (1) {
+            /* refreshR, decodeCL.c:25-41 */
+            for (int64_t e = 0; e < E; ++e) {
+                const int32_t row = g->rows[e];
+                float d = 1;
+                for (int32_t p = g->row_ptr[row]; p < g->row_ptr[row + 1]; ++p) {
+                    if (p == e) continue;
+                    d *= q0[p] - q1[p];
+                }
+                r0[e] = (1 + d) / 2;
+                r1[e] = (1 - d) / 2;
+            }
+            /* hardDecision, decodeCL.c:64-86: ties and NaN keep the old bit */
+            for (int32_t n = 0; n < N; ++n) {
+                float t0 = p0[n], t1 = p1[n];
+                for (int32_t p = g->col_ptr[n]; p < g->col_ptr[n + 1]; ++p) {
+                    t0 *= r0[g->col_edge[p]];
+                    t1 *= r1[g->col_edge[p]];
+                }
+                if (t0 > t1) src[n] = 0;
+                else if (t0 < t1) src[n] = 1;
+            }
+            const int flag = syndrome_fails(g, src); /* checkResult :88-108 */
+            ++time;
+            if (taps && taps->iter == time) {
+                tap_copy(taps->r0, f, E, r0);
+                tap_copy(taps->r1, f, E, r1);
+            }
+            if (!flag) break;              /* MyLdpc.cpp:1031-1039 */
+            if (time == max_iter) break;
+            /* refreshQ, decodeCL.c:43-62 */
+            for (int64_t e = 0; e < E; ++e) {
+                const int32_t col = g->cols[e];
+                float t0 = p0[col], t1 = p1[col];
+                for (int32_t p = g->col_ptr[col]; p < g->col_ptr[col + 1]; ++p) {
+                    const int32_t o = g->col_edge[p];
+                    if (o == e) continue;
+                    t0 *= r0[o];
+                    t1 *= r1[o];
+                }
+                q0[e] = t0 / (t0 + t1);
+                q1[e] = t1 / (t0 + t1);
+            }
+            if (taps && taps->iter == time) {
+                tap_copy(taps->q0, f, E, q0);
+                tap_copy(taps->q1, f, E, q1);
+            }
+        }
+        if (iters) iters[f] = time;
+        if (hard_out) memcpy(hard_out + f * N, src, (size_t)N);
+        pack_frame(g, src, f, pack_mode, out, out_bytes);
+    }
+    free(q0); free(q1); free(r0); free(r1); free(p0); free(p1); free(src);
+    return 0;
+}
+
+/* ------------------------------------------------------- layered min-sum */
+
+/* OpenCL sign(): 1 for x > 0, -1 for x < 0, +-0 for +-0, 0 for NaN. */
+static float cl_sign(float x)
+{
+    if (x > 0.0f) return 1.0f;
+    if (x < 0.0f) return -1.0f;
+    if (x == 0.0f) return x;
+    return 0.0f;
+}
+
+int oracle_decode_layered(const oracle_graph *g, int32_t layer_rows, const float *y,
+                          int64_t frames, int max_iter, int pack_mode, uint8_t *out,
+                          int64_t out_bytes, int32_t *iters, uint8_t *hard_out,
+                          const oracle_taps *taps, uint8_t *undefined_frames)
+{
+    const int64_t E = g->E;
+    const int32_t N = g->N, M = g->M;
+    if (layer_rows <= 0 || M % layer_rows) return -1;
+    float *lP = (float *)malloc(sizeof(float) * (size_t)N);
+    float *lR = (float *)malloc(sizeof(float) * (size_t)E);
+    uint8_t *src = (uint8_t *)calloc((size_t)N, 1);
+    if (!lP || !lR || !src) return -2;
+
+    for (int64_t f = 0; f < frames; ++f) {
+        const float *yf = y + f * N;
+        int time = 0;
+        if (undefined_frames) undefined_frames[f] = 0;
+        memcpy(lP, yf, sizeof(float) * (size_t)N);         /* decodeCL.c:331-334 */
+        for (int64_t e = 0; e < E; ++e) lR[e] = 0;         /* :336-340 */
+        while (1) {
+            /* one pass over all layers, decodeCL.c:345-386.  Rows of a layer
+             * touch disjoint columns, so their order inside a layer is free. */
+            for (int32_t row = 0; row < M; ++row) {
+                const int32_t lo = g->row_ptr[row], hi = g->row_ptr[row + 1];
+                float a = 1, b = 1000, c = 1001;
+                int32_t bInd = -1;
+                for (int32_t p = lo; p < hi; ++p) {        /* :352-367 */
+                    float tmp = lP[g->cols[p]] - lR[p];
+                    lR[p] = cl_sign(tmp);
+                    a *= tmp;
+                    lP[g->cols[p]] = tmp;
+                    tmp = fabsf(tmp);
+                    if (tmp <= b) { c = b; b = tmp; bInd = p; }
+                    else if (tmp > b && tmp <= c) { c = tmp; }
+                }
+                /* The reference declares `char bInd;` without a value (:349); when
+                 * no |Q| of the row is <= 1000 it is read uninitialised (:372) --
+                 * undefined behaviour.  We define that case as "no edge takes the
+                 * second minimum" (every edge gets a*b = +-1000) and flag the frame
+                 * so fixtures made from the reference kernel can leave it out. */
+                if (bInd < 0 && hi > lo && undefined_frames) undefined_frames[f] = 1;
+                a = cl_sign(a);                            /* :369 */
+                for (int32_t p = lo; p < hi; ++p)          /* :371-379 */
+                    lR[p] *= (p == bInd) ? a * c : a * b;
+                for (int32_t p = lo; p < hi; ++p)          /* :381-383 */
+                    lP[g->cols[p]] += lR[p];
+            }
+            for (int32_t n = 0; n < N; ++n) src[n] = lP[n] < 0;   /* :388-389 */
+            const int flag = syndrome_fails(g, src);              /* :393-404 */
+            ++time;
+            if (taps && taps->iter == time) {
+                tap_copy(taps->r, f, E, lR);
+                tap_copy(taps->post, f, N, lP);
+            }
+            if (!flag) break;                                     /* :407-410 */
+            if (time == max_iter) break;
+        }
+        if (iters) iters[f] = time;
+        if (hard_out) memcpy(hard_out + f * N, src, (size_t)N);
+        pack_frame(g, src, f, pack_mode, out, out_bytes);
+    }
+    free(lP); free(lR); free(src);
+    return 0;
+}
+
+/* ------------------------------------------------------------ test channel */
+
+/* gaussian(), MyLdpc.cpp:1093-1105: Box-Muller on libc rand(), pi truncated to
+ * 3.1415926.  The reference is C++: sqrt/log/cos on float arguments resolve to
+ * the float overloads, so the restatement calls sqrtf/logf/cosf. */
+static float box_muller(float ave, float sd)
+{
+    const float pi = 3.1415926f;
+    const float s1 = (float)((1.0 + rand()) / (RAND_MAX + 1.0));
+    const float s2 = (float)((1.0 + rand()) / (RAND_MAX + 1.0));
+    const float r = sqrtf(-2 * logf(s2));
+    const float t = 2 * pi * s1;
+    const float z = r * cosf(t);
+    return ave + z * sd;
+}
+
+/* Coder::test, MyLdpc.cpp:1061-1078: bit 0 -> +1.0, bit 1 -> -1.0, then noise. */
+void oracle_test_channel(const uint8_t *prior, float *post, int64_t prior_len, float sd)
+{
+    for (int64_t c = 0; c < prior_len; ++c)
+        for (int b = 0; b < 8; ++b)
+            post[c * 8 + b] = (prior[c] & (1u << b)) ? -1.0f : 1.0f;
+    for (int64_t i = 0; i < prior_len * 8; ++i) post[i] += box_muller(0, sd);
+}
