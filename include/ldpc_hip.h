@@ -1,0 +1,158 @@
+/*
+ * ldpc_hip.h -- C ABI of libldpc_hip.so: batched LDPC belief-propagation decoding
+ * on AMD MI355X (gfx950), hand-written HIP kernels.
+ *
+ * This is the drop-in boundary for the decode hot path of wing02/MyLdpcCppApi.
+ * The reference has no FFI layer: its boundary is the C++ class `Coder`
+ * (MyLdpc.h:104-238) whose decode() (MyLdpc.cpp:571-618) drives OpenCL kernels
+ * (decodeCL.c).  Each entry point below names the reference interface it
+ * replaces.  include/MyLdpc.h + csrc/MyLdpc.cpp re-create `Coder` on top of this
+ * ABI; INTEGRATION.md shows the binding.
+ *
+ * Conventions (all taken from the reference):
+ *   - H is given as its nonzeros in ROW-MAJOR order; edge id = rank in that
+ *     order (MyLdpc.cpp:186-219).  fp32 reductions follow the reference's
+ *     orders: ascending edge id along a row and along a column.
+ *   - channel values `llr`: N floats per frame, frame-major, +1 <-> bit 0,
+ *     -1 <-> bit 1 (MyLdpc.cpp:1066-1069).
+ *   - output: the first K hard bits of every frame, LSB-first
+ *     (decodeCL.c:188-199 / MyLdpc.cpp:765-774).
+ *   - every function returns 0 on success (LDPC_SUCCESS == 0, MyLdpc.h:24) and
+ *     a positive LDPC_ERR_* code otherwise; it never exits the process
+ *     (the reference calls exit(0), MyLdpc.cpp:243-254).  ldpc_last_error()
+ *     returns the message of the calling thread's last failure.
+ *   - a decoder handle is not re-entrant (neither is Coder, MyLdpc.h:184-236):
+ *     one handle per host thread / stream.
+ *
+ * There is no CPU fallback: without a usable HIP device every compute entry
+ * point fails with LDPC_ERR_HIP.
+ */
+#ifndef LDPC_HIP_H_
+#define LDPC_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDPC_HIP_ABI_VERSION 1
+
+enum ldpc_status {
+    LDPC_OK = 0,
+    LDPC_ERR_ARG = 1,         /* bad argument (message says which)            */
+    LDPC_ERR_HIP = 2,         /* HIP runtime error / no device                */
+    LDPC_ERR_NOMEM = 3,
+    LDPC_ERR_UNSUPPORTED = 4, /* valid request this build cannot serve        */
+    LDPC_ERR_STATE = 5        /* call order / handle misuse                   */
+};
+
+/* decodeType of the reference (MyLdpc.h:37-39) maps as:
+ *   DecodeSP                 -> LDPC_ALGO_SP       (decodeCL.c:3-108)
+ *   DecodeMS, DecodeCPU      -> LDPC_ALGO_MS       (decodeCL.c:113-186, MyLdpc.cpp:684-784)
+ *   DecodeTDMP, DecodeTDMPCL -> LDPC_ALGO_LAYERED  (semantics of decodeCL.c:307-426) */
+enum ldpc_algo {
+    LDPC_ALGO_SP = 0,      /* flooding sum-product, probability domain, fp32     */
+    LDPC_ALGO_MS = 1,      /* flooding min-sum, fp32                             */
+    LDPC_ALGO_LAYERED = 2  /* layered (TDMP) min-sum                             */
+};
+
+enum ldpc_msg_dtype { LDPC_MSG_F32 = 0, LDPC_MSG_F16 = 1 };
+
+enum ldpc_pack_mode {
+    LDPC_PACK_BYTES = 0, /* toChar, decodeCL.c:188-199: K/8 whole bytes per frame at (frame*K)/8 */
+    LDPC_PACK_BITS = 1   /* decodeCPU, MyLdpc.cpp:765-774: bit i of frame b at bit b*K+i         */
+};
+
+typedef struct ldpc_graph ldpc_graph;
+typedef struct ldpc_decoder ldpc_decoder;
+
+typedef struct ldpc_decoder_config {
+    uint32_t struct_size;   /* = sizeof(ldpc_decoder_config); ABI guard                    */
+    int32_t K;              /* information bits per frame (ldpcK)                          */
+    int32_t max_batch;      /* frames per launch group (forDecoder's batchSize)            */
+    int32_t algo;           /* enum ldpc_algo                                              */
+    int32_t msg_dtype;      /* enum ldpc_msg_dtype                                         */
+    int32_t max_iter;       /* `times`, MyLdpc.cpp:24 (reference: 40)                      */
+    float llr_scale;        /* SP only: q = exp(llr_scale*y)..., decodeCL.c:9 (reference: 8) */
+    int32_t early_term;     /* 1: frames freeze when their syndrome is clean (reference
+                               behaviour, decodeCL.c:27,48-49); 0: always run max_iter      */
+    int32_t device;         /* HIP device ordinal                                          */
+    int32_t layer_rows;     /* LDPC_ALGO_LAYERED: rows per layer (z)                       */
+    int32_t pack_mode;      /* enum ldpc_pack_mode                                         */
+    int32_t frames_per_lane;/* tuning: 0 = auto, else 1, 2 or 4 (tile = 64*frames_per_lane) */
+    int32_t poll_interval;  /* early_term: host checks "all frames done" every this many
+                               iterations (0 = never; finished tiles still skip on device)  */
+    int32_t reserved[8];    /* must be 0                                                   */
+} ldpc_decoder_config;
+
+typedef struct ldpc_decode_stats {
+    int32_t iterations_launched; /* check/variable rounds enqueued by the last call          */
+    int32_t batch_time;          /* the reference's `Time=` (MyLdpc.cpp:838,1048): max iters  */
+    int64_t frames;              /* frames of the last call                                  */
+    int64_t frames_converged;    /* frames whose syndrome was clean                          */
+    float ms_total;              /* HIP-event time of the whole decode on its stream         */
+    float ms_check;              /* summed check-node kernels (needs timing enabled)         */
+    float ms_var;                /* summed variable-node kernels                             */
+    float ms_other;              /* init / pack / bookkeeping kernels                        */
+    int32_t launches_check;      /* kernel launches behind ms_check                          */
+    int32_t launches_var;
+} ldpc_decode_stats;
+
+/* ---- library -------------------------------------------------------------- */
+int ldpc_abi_version(void);
+const char *ldpc_last_error(void);
+/* Number of HIP devices (0 and LDPC_ERR_HIP if the runtime is unusable). */
+int ldpc_device_count(int *count);
+
+/* ---- graph: replaces Coder::forDecoder's adjacency build, MyLdpc.cpp:171-222 ---- */
+/* rows/cols: the E nonzeros of the M x N parity-check matrix in row-major order
+ * (strictly ascending (row, col)).  Host-only; no device is touched. */
+int ldpc_graph_create(const int32_t *rows, const int32_t *cols, int64_t E, int32_t M, int32_t N,
+                      ldpc_graph **out);
+int ldpc_graph_destroy(ldpc_graph *g);
+int ldpc_graph_info(const ldpc_graph *g, int32_t *M, int32_t *N, int64_t *E, int32_t *max_row_deg,
+                    int32_t *max_col_deg);
+
+/* ---- decoder: replaces Coder::forDecoder's device setup + addDecodeType,
+ *      MyLdpc.cpp:226-305, 307-552 -------------------------------------------- */
+void ldpc_decoder_config_init(ldpc_decoder_config *cfg); /* reference defaults */
+int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldpc_decoder **out);
+int ldpc_decoder_destroy(ldpc_decoder *d);
+
+/* ---- decode: replaces Coder::decode + decodeOnceSP/MS/TDMP*, MyLdpc.cpp:571-618,
+ *      786-1059.  Host buffers; chunks `frames` into max_batch groups; blocking.
+ *      out must hold ldpc_out_bytes(K, frames, pack_mode) bytes.
+ *      iters (nullable): per frame, the iteration at which its syndrome first was
+ *      clean, or max_iter. ------------------------------------------------------- */
+int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t *out_host,
+                int64_t out_bytes, int32_t *iters);
+
+/* Same, on buffers already resident in this decoder's device memory; enqueued on
+ * `stream` (a hipStream_t, NULL = default stream), returns without waiting unless
+ * poll_interval > 0.  frames <= max_batch.  iters_dev nullable. */
+int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, uint8_t *out_dev,
+                       int64_t out_bytes, int32_t *iters_dev, void *stream);
+
+int64_t ldpc_out_bytes(int32_t K, int64_t frames, int32_t pack_mode);
+
+/* Per-kernel HIP-event timing of subsequent decode calls (adds event records;
+ * off by default).  Stats of the last call; blocks until that call has finished. */
+int ldpc_decoder_set_timing(ldpc_decoder *d, int enable);
+int ldpc_decoder_stats(ldpc_decoder *d, ldpc_decode_stats *stats);
+
+/* ---- debug taps (tolerance checks against the oracle) ------------------------
+ * Stop the NEXT decode call after `iter` check/variable rounds (0 = off) and keep
+ * its messages.  ldpc_decoder_dump then copies them out in the reference's layout
+ * [frame][E] / [frame][N] (decodeCL.c: q/r at b*nonZeros+e, posteriors at b*N+n).
+ * which: 0 = check->variable messages R (SP: r0-r1), 1 = variable->check
+ * messages Q (SP: q0-q1), 2 = channel term (SP: exp(scale*y), MS: y; layered:
+ * posterior P), 3 = hard bits as floats 0/1 [frame][N]. */
+int ldpc_decoder_set_tap(ldpc_decoder *d, int32_t iter);
+int ldpc_decoder_dump(ldpc_decoder *d, int32_t which, float *host_out, int64_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDPC_HIP_H_ */

@@ -1,0 +1,308 @@
+/*
+ * MyLdpc.cpp -- class Coder of wing02/MyLdpcCppApi re-created above the MI355X
+ * C ABI (include/ldpc_hip.h).  Host-side C++ only: every decode runs in the HIP
+ * kernels of libldpc_hip.so.  Reference lines are cited per method.
+ */
+#include "../../include/MyLdpc.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "wimax_seeds.h"
+
+namespace {
+const int kSeedCols = WIMAX_NB;
+}
+
+int Coder::fail(int code, const std::string &msg)
+{
+    err = msg;
+    return code ? code : LDPC_FAIL;
+}
+
+/* MyLdpc.cpp:20-29 */
+Coder::Coder(int ldpcK, int ldpcN, enum rate_type rate)
+    : times(40), llrScale(8.0f), device(0), hSeed(nullptr), seedRowLength(0), ldpcK(ldpcK),
+      ldpcN(ldpcN), ldpcM(ldpcN - ldpcK), z(0), nonZeros(0), batchSize(0), rate(rate),
+      isEncoder(false), isDecoder(false), lastTime(0), encX(-1), structured(false), graph(nullptr),
+      cpuDecoderBatch(0)
+{
+    initCheckMatrix();
+}
+
+Coder::~Coder()
+{
+    for (auto &kv : decoders) ldpc_decoder_destroy(kv.second);
+    if (graph) ldpc_graph_destroy(graph);
+}
+
+/* MyLdpc.cpp:52-135.  The triplet list + Eigen setFromTriplets become a direct
+ * row-major listing: within a row the blocks come in ascending block column. */
+int Coder::initCheckMatrix()
+{
+    z = ldpcN / n_b;                                        /* :55 */
+    const int r = (int)rate;
+    if (r < 0 || r >= WIMAX_NUM_RATES || z <= 0 || z * n_b != ldpcN)
+        return fail(LDPC_ERR_ARG, "Coder: N must be a positive multiple of 24 and rate one of the six seeds");
+    hSeed = wimax_seed_table[r];
+    seedRowLength = wimax_seed_rows[r];                     /* :58-83 */
+    if (ldpcM != seedRowLength * z)
+        return fail(LDPC_ERR_ARG, "Coder: N-K does not match the rate's seed matrix");
+    shift.assign((size_t)seedRowLength * kSeedCols, -1);
+    for (int i = 0; i < seedRowLength * kSeedCols; ++i) {
+        int p = hSeed[i];
+        if (p >= 0) shift[i] = (rate != rate_2_3_a) ? p * z / WIMAX_Z0 : p % z;   /* :89-94 */
+    }
+    rows.clear(); cols.clear();
+    rowRange.assign((size_t)ldpcM + 1, 0);
+    for (int sr = 0; sr < seedRowLength; ++sr)
+        for (int pr = 0; pr < z; ++pr) {
+            rowRange[(size_t)sr * z + pr] = (int)rows.size();
+            for (int sc = 0; sc < kSeedCols; ++sc) {
+                const int p = shift[(size_t)sr * kSeedCols + sc];
+                if (p < 0) continue;
+                rows.push_back(sr * z + pr);                /* (z + c - r) % z == p, :97 */
+                cols.push_back(sc * z + (pr + p) % z);
+            }
+        }
+    rowRange[ldpcM] = (int)rows.size();
+    nonZeros = (int)rows.size();                            /* :109 */
+    return LDPC_SUCCESS;
+}
+
+/* Length helpers, MyLdpc.cpp:620-631. */
+int Coder::getPriorCodeLength(int srcLength) { return (srcLength + (ldpcK / 8) - 1) / (ldpcK / 8) * (ldpcN / 8); }
+int Coder::getPostCodeLength(int srcLength) { return (srcLength + (ldpcK / 8) - 1) / (ldpcK / 8) * ldpcN; }
+int Coder::getCodeSize(int srcLength) { return (srcLength + (ldpcK / 8) - 1) / (ldpcK / 8); }
+
+/* ----------------------------------------------------------------- encoder */
+
+/* forEncoder, MyLdpc.cpp:137-165.  The reference inverts dense (M-z)^2 int
+ * matrices (Richardson-Urbanke with gap z), which cannot scale past a few
+ * thousand bits.  A systematic codeword is unique once H's parity part is
+ * nonsingular, so any exact solver of H [s p]^T = 0 gives the same bytes.  The
+ * 802.16e seeds have a weight-3 parity block column (rows 0, x, mb-1; equal
+ * outer shifts, middle shift 0) followed by a dual diagonal, which solves in
+ * O(E): p1 = sum of all block rows of A s, then forward substitution. */
+int Coder::forEncoder()
+{
+    if (!hSeed) return fail(LDPC_ERR_STATE, "Coder was not constructed");
+    const int mb = seedRowLength, kb = kSeedCols - mb;
+    structured = true;
+    encX = -1;
+    int cnt = 0;
+    for (int i = 0; i < mb; ++i) {
+        const int p = shift[(size_t)i * kSeedCols + kb];
+        if (p < 0) continue;
+        ++cnt;
+        if (i != 0 && i != mb - 1) { if (p != 0 || encX >= 0) structured = false; encX = i; }
+    }
+    if (cnt != 3 || encX < 0 || shift[kb] < 0 || shift[(size_t)(mb - 1) * kSeedCols + kb] != shift[kb])
+        structured = false;
+    for (int j = 0; j < mb - 1 && structured; ++j)
+        for (int i = 0; i < mb; ++i) {
+            const int p = shift[(size_t)i * kSeedCols + kb + 1 + j];
+            const bool want = (i == j || i == j + 1);
+            if (want ? (p != 0) : (p >= 0)) { structured = false; break; }
+        }
+    if (!structured) {
+        /* generic fallback: bit-packed Gauss-Jordan inverse of the M x M parity part */
+        const int M = ldpcM;
+        if (M > 8192) return fail(LDPC_ERR_UNSUPPORTED, "forEncoder: unstructured parity part too large");
+        const size_t W = ((size_t)2 * M + 63) / 64;
+        std::vector<unsigned long long> a((size_t)M * W, 0ull);
+        for (int e = 0; e < nonZeros; ++e)
+            if (cols[e] >= ldpcK) {
+                const int c = cols[e] - ldpcK;
+                a[(size_t)rows[e] * W + c / 64] |= 1ull << (c % 64);
+            }
+        for (int i = 0; i < M; ++i) a[(size_t)i * W + (M + i) / 64] |= 1ull << ((M + i) % 64);
+        for (int c = 0; c < M; ++c) {
+            int piv = -1;
+            for (int r2 = c; r2 < M; ++r2)
+                if (a[(size_t)r2 * W + c / 64] >> (c % 64) & 1ull) { piv = r2; break; }
+            if (piv < 0) return fail(LDPC_ERR_UNSUPPORTED, "forEncoder: parity part of H is singular");
+            if (piv != c)
+                for (size_t w = 0; w < W; ++w) std::swap(a[(size_t)piv * W + w], a[(size_t)c * W + w]);
+            for (int r2 = 0; r2 < M; ++r2)
+                if (r2 != c && (a[(size_t)r2 * W + c / 64] >> (c % 64) & 1ull))
+                    for (size_t w = 0; w < W; ++w) a[(size_t)r2 * W + w] ^= a[(size_t)c * W + w];
+        }
+        denseInv.assign((size_t)M * M, 0);
+        for (int i = 0; i < M; ++i)
+            for (int j = 0; j < M; ++j)
+                denseInv[(size_t)i * M + j] = (unsigned char)(a[(size_t)i * W + (M + j) / 64] >> ((M + j) % 64) & 1ull);
+    }
+    isEncoder = true;
+    return LDPC_SUCCESS;
+}
+
+/* encode, MyLdpc.cpp:554-569: frame f reads srcCode + f*K/8 and writes priorCode
+ * + f*N/8; the last frame may be short (zero-padded, :639-650). */
+int Coder::encode(char *srcCode, char *priorCode, int srcLength)
+{
+    if (!isEncoder) return fail(LDPC_ERR_STATE, "encode: call forEncoder() first");
+    if (!srcCode || !priorCode || srcLength <= 0) return fail(LDPC_ERR_ARG, "encode: bad arguments");
+    for (int offset = 0;; ++offset) {
+        if ((offset + 1) * (ldpcK / 8) < srcLength) {
+            encodeOnce(&srcCode[offset * (ldpcK / 8)], &priorCode[offset * (ldpcN / 8)], ldpcK / 8);
+        } else {
+            encodeOnce(&srcCode[offset * (ldpcK / 8)], &priorCode[offset * (ldpcN / 8)],
+                       srcLength - offset * (ldpcK / 8));
+            break;
+        }
+    }
+    return LDPC_SUCCESS;
+}
+
+/* encodeOnce, MyLdpc.cpp:633-682.  Output layout [K info | z p1 | M-z p2],
+ * LSB-first bits (:661-680). */
+int Coder::encodeOnce(const char *src, char *code, int srcLength)
+{
+    const int mb = seedRowLength, kb = kSeedCols - mb;
+    std::vector<unsigned char> s((size_t)ldpcK, 0), par((size_t)ldpcM, 0);
+    for (int c = 0; c < ldpcK / 8 && c < srcLength; ++c)         /* :641-650 */
+        for (int b = 0; b < 8; ++b) s[(size_t)8 * c + b] = ((unsigned char)src[c] >> b) & 1;
+    /* lambda_i = (A s) restricted to block row i */
+    std::vector<unsigned char> lam((size_t)ldpcM, 0);
+    for (int i = 0; i < mb; ++i)
+        for (int j = 0; j < kb; ++j) {
+            const int p = shift[(size_t)i * kSeedCols + j];
+            if (p < 0) continue;
+            for (int r = 0; r < z; ++r) lam[(size_t)i * z + r] ^= s[(size_t)j * z + (r + p) % z];
+        }
+    if (structured) {
+        unsigned char *p1 = par.data();
+        for (int i = 0; i < mb; ++i)
+            for (int r = 0; r < z; ++r) p1[r] ^= lam[(size_t)i * z + r];
+        const int h0 = shift[kb];
+        /* v_1 = lambda_0 + P(h0) p1 ; v_{i+1} = lambda_i + v_i (+ p1 at row x) */
+        for (int r = 0; r < z; ++r) par[(size_t)z + r] = lam[r] ^ p1[(r + h0) % z];
+        for (int i = 1; i <= mb - 2; ++i)
+            for (int r = 0; r < z; ++r)
+                par[(size_t)(i + 1) * z + r] = lam[(size_t)i * z + r] ^ par[(size_t)i * z + r] ^
+                                              ((i == encX) ? p1[r] : 0);
+    } else {
+        for (int i = 0; i < ldpcM; ++i) {
+            unsigned char acc = 0;
+            for (int j = 0; j < ldpcM; ++j) acc ^= denseInv[(size_t)i * ldpcM + j] & lam[j];
+            par[i] = acc;
+        }
+    }
+    /* the reference copies the source with strncpy (:661), which stops at a NUL
+     * byte; the intent -- and this code -- is a plain copy */
+    memcpy(code, src, (size_t)srcLength);
+    memset(code + srcLength, 0, (size_t)(ldpcN / 8 - srcLength));
+    for (int i = 0; i < ldpcM; ++i)
+        if (par[i]) {
+            const int off = ldpcK + i;
+            code[off / 8] |= (char)(1 << (off % 8));
+        }
+    return LDPC_SUCCESS;
+}
+
+/* ----------------------------------------------------------------- decoder */
+
+/* forDecoder, MyLdpc.cpp:167-305: the adjacency lists become an ldpc_graph; the
+ * OpenCL context/program/buffers become decoder handles made in addDecodeType. */
+int Coder::forDecoder(int batchSize)
+{
+    if (!hSeed) return fail(LDPC_ERR_STATE, "Coder was not constructed");
+    if (batchSize <= 0) return fail(LDPC_ERR_ARG, "forDecoder: batchSize must be positive");
+    this->batchSize = batchSize;
+    if (!graph) {
+        int rc = ldpc_graph_create(rows.data(), cols.data(), nonZeros, ldpcM, ldpcN, &graph);
+        if (rc) return fail(rc, ldpc_last_error());
+    }
+    isDecoder = true;
+    return LDPC_SUCCESS;
+}
+
+/* addDecodeType, MyLdpc.cpp:307-552. */
+int Coder::addDecodeType(enum decodeType deType)
+{
+    if (!isDecoder) return fail(LDPC_ERR_STATE, "addDecodeType: call forDecoder() first");
+    if (deType == DecodeMSCL)
+        return fail(LDPC_ERR_UNSUPPORTED, "DecodeMSCL (fused short-code min-sum, decodeCL.c:432-567) is not built");
+    if (decoders.count((int)deType)) return LDPC_SUCCESS;
+    if (deType == DecodeCPU) return LDPC_SUCCESS;   /* made on first use: needs the stream length (:438-439 is a no-op too) */
+    ldpc_decoder_config cfg;
+    ldpc_decoder_config_init(&cfg);
+    cfg.K = ldpcK;
+    cfg.max_batch = batchSize;
+    cfg.max_iter = times;
+    cfg.llr_scale = llrScale;
+    cfg.device = device;
+    cfg.early_term = 1;
+    cfg.poll_interval = 4;
+    cfg.pack_mode = LDPC_PACK_BYTES;
+    cfg.layer_rows = z;
+    cfg.algo = (deType == DecodeSP) ? LDPC_ALGO_SP : (deType == DecodeMS) ? LDPC_ALGO_MS : LDPC_ALGO_LAYERED;
+    ldpc_decoder *d = nullptr;
+    int rc = ldpc_decoder_create(graph, &cfg, &d);
+    if (rc) return fail(rc, ldpc_last_error());
+    decoders[(int)deType] = d;
+    return LDPC_SUCCESS;
+}
+
+/* decode, MyLdpc.cpp:571-618: the frame stream is cut into batchSize groups by
+ * ldpc_decode.  srcLength bytes are written. */
+int Coder::decode(float *postCode, char *srcCode, int srcLength, enum decodeType deType)
+{
+    if (!isDecoder) return fail(LDPC_ERR_STATE, "decode: call forDecoder() first");
+    if (!postCode || !srcCode || srcLength <= 0) return fail(LDPC_ERR_ARG, "decode: bad arguments");
+    const int codeSize = getCodeSize(srcLength);
+    ldpc_decoder *d = nullptr;
+    if (deType == DecodeCPU) {
+        /* decodeCPU, MyLdpc.cpp:684-784: one pass over the whole stream, bit-offset packing */
+        if (!decoders.count((int)DecodeCPU) || cpuDecoderBatch < codeSize) {
+            if (decoders.count((int)DecodeCPU)) ldpc_decoder_destroy(decoders[(int)DecodeCPU]);
+            decoders.erase((int)DecodeCPU);
+            ldpc_decoder_config cfg;
+            ldpc_decoder_config_init(&cfg);
+            cfg.K = ldpcK; cfg.max_batch = codeSize; cfg.max_iter = times; cfg.device = device;
+            cfg.algo = LDPC_ALGO_MS; cfg.pack_mode = LDPC_PACK_BITS; cfg.early_term = 1; cfg.poll_interval = 4;
+            int rc = ldpc_decoder_create(graph, &cfg, &d);
+            if (rc) return fail(rc, ldpc_last_error());
+            decoders[(int)DecodeCPU] = d;
+            cpuDecoderBatch = codeSize;
+        }
+        d = decoders[(int)DecodeCPU];
+        memset(srcCode, 0, (size_t)srcLength);               /* :685 */
+    } else {
+        auto it = decoders.find((int)deType);
+        if (it == decoders.end()) return fail(LDPC_ERR_STATE, "decode: addDecodeType() was not called for this type");
+        d = it->second;
+    }
+    int rc = ldpc_decode(d, postCode, codeSize, (uint8_t *)srcCode, srcLength, nullptr);
+    if (rc) return fail(rc, ldpc_last_error());
+    ldpc_decode_stats st;
+    if (ldpc_decoder_stats(d, &st) == LDPC_OK) lastTime = st.batch_time;
+    return LDPC_SUCCESS;
+}
+
+/* ------------------------------------------------------------ test channel */
+
+/* gaussian, MyLdpc.cpp:1093-1105.  C++ overloads: sqrt/log/cos on float. */
+float gaussian(float ave, float sd)
+{
+    const float pi = 3.1415926f;
+    const float s1 = (float)((1.0 + rand()) / (RAND_MAX + 1.0));
+    const float s2 = (float)((1.0 + rand()) / (RAND_MAX + 1.0));
+    const float r = std::sqrt(-2 * std::log(s2));
+    const float t = 2 * pi * s1;
+    const float zz = r * std::cos(t);
+    return ave + zz * sd;
+}
+
+/* test, MyLdpc.cpp:1061-1078 */
+int Coder::test(char *priorCode, float *postCode, int priorCodeLength, float rate)
+{
+    if (!priorCode || !postCode || priorCodeLength < 0) return fail(LDPC_ERR_ARG, "test: bad arguments");
+    for (int c = 0; c < priorCodeLength; ++c)
+        for (int b = 0; b < 8; ++b)
+            postCode[c * 8 + b] = (priorCode[c] & (1 << b)) ? -1.0f : 1.0f;
+    for (int i = 0; i < priorCodeLength * 8; ++i) postCode[i] += gaussian(0, rate);
+    return LDPC_SUCCESS;
+}

@@ -1,0 +1,661 @@
+/*
+ * flood_kernels.hpp -- gfx950 kernels for two-phase (flooding) LDPC belief
+ * propagation: sum-product in the probability domain and min-sum, fp32.
+ *
+ * Replaces the reference's kernel chain (decodeCL.c):
+ *   check_kernel<SP>  <- refreshR        decodeCL.c:25-41
+ *   var_kernel<SP>    <- hardDecision    decodeCL.c:64-86  + refreshQ :43-62
+ *   check_kernel<MS>  <- refreshRMS      decodeCL.c:126-147
+ *   syndrome_kernel   <- checkResult     decodeCL.c:88-108
+ *   var_kernel<MS>    <- refreshPostPMS  decodeCL.c:149-171 + refreshQMS :175-186
+ *   init_kernel       <- decodeInit :3-22 / decodeInitMS :113-124
+ *   pack_kernel       <- toChar :188-199 (and decodeCPU's bit packing MyLdpc.cpp:765-774)
+ *
+ * Design (MI355X-first, not the reference's layout):
+ *   - The reference indexes messages [frame][edge] with the frame as NDRange
+ *     dim 0, so adjacent work-items are E floats apart, and every edge re-walks
+ *     its whole row/column (O(d^2) reads).  Here FRAMES ARE THE LANES: a tile is
+ *     F = 64*V frames (V = 1, 2 or 4 frames per lane) and every per-edge message
+ *     of a tile is one contiguous F*4-byte segment, msg[tile][edge][F].  A
+ *     wave-instruction moves one whole segment (256 B .. 1 KiB, 16 B per lane at
+ *     V = 4), H's indices are wave-uniform (scalar loads, SGPRs), each message is
+ *     read once and written once per half-iteration, and the check / variable
+ *     reductions are per-lane register chains -- no cross-lane traffic, no LDS,
+ *     no MFMA (sparse gather/reduce, HBM-bound).
+ *   - Check phase: a row's edges are consecutive edge ids, so it streams.
+ *     Variable phase: a column's edges are gathered/scattered as whole segments.
+ *   - fp32 results are bit-identical to the reference's operation order:
+ *     products/sums run left to right in ascending edge id with the own edge
+ *     skipped (prefix shared, tail recomputed), IEEE division, no FMA
+ *     contraction (compile with -ffp-contract=off).
+ *   - SP messages are stored as ONE float per edge and direction: the reference
+ *     only ever consumes q0-q1 (decodeCL.c:37) and r0 = (1+d)/2, r1 = (1-d)/2 are
+ *     exact functions of d (:39-40), so storing d_q = fl(q0-q1) and d_r = d loses
+ *     nothing: 16*E + 4*N bytes per frame-iteration.
+ *   - Hard bits live as bit masks hard[tile][n][V] (bit l of word v = frame
+ *     V*l+v): the row syndrome is an XOR of wave-uniform 64-bit words.
+ */
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ldpc_expf.h"
+
+namespace ldpc {
+
+constexpr int kAlgoSP = 0;
+constexpr int kAlgoMS = 1;
+constexpr int kBlock = 256;          /* 4 waves */
+constexpr int kWavesPerBlock = 4;
+constexpr int kMaxUnrolledDegree = 16;
+
+/* ---- V-wide per-lane vectors --------------------------------------------- */
+template <int V> __device__ __forceinline__ void vload(float (&d)[V], const float *p);
+template <> __device__ __forceinline__ void vload<1>(float (&d)[1], const float *p) { d[0] = *p; }
+template <> __device__ __forceinline__ void vload<2>(float (&d)[2], const float *p)
+{
+    const float2 t = *reinterpret_cast<const float2 *>(p);
+    d[0] = t.x; d[1] = t.y;
+}
+template <> __device__ __forceinline__ void vload<4>(float (&d)[4], const float *p)
+{
+    const float4 t = *reinterpret_cast<const float4 *>(p);
+    d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+}
+template <int V> __device__ __forceinline__ void vstore(float *p, const float (&s)[V]);
+template <> __device__ __forceinline__ void vstore<1>(float *p, const float (&s)[1]) { *p = s[0]; }
+template <> __device__ __forceinline__ void vstore<2>(float *p, const float (&s)[2])
+{
+    *reinterpret_cast<float2 *>(p) = make_float2(s[0], s[1]);
+}
+template <> __device__ __forceinline__ void vstore<4>(float *p, const float (&s)[4])
+{
+    *reinterpret_cast<float4 *>(p) = make_float4(s[0], s[1], s[2], s[3]);
+}
+
+__device__ __forceinline__ int wave_id_in_block()
+{
+    return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
+
+template <int V> __device__ __forceinline__ bool tile_finished(const uint64_t *done, int tile)
+{
+    bool all = true;
+#pragma unroll
+    for (int v = 0; v < V; ++v) all = all && (done[(size_t)tile * V + v] == ~0ull);
+    return all;
+}
+
+/* ========================================================================= */
+/*                               check node                                   */
+/* ========================================================================= */
+
+struct CheckArgs {
+    const float *__restrict__ Q;         /* [T][E][F] variable->check          */
+    float *__restrict__ R;               /* [T][E][F] check->variable          */
+    const int32_t *__restrict__ cls_e0;  /* [n_rows] first edge id of each row of this degree class */
+    const uint64_t *__restrict__ done;   /* [T][V] frozen frames                */
+    int64_t E;
+    int32_t n_rows;
+    int32_t rows_per_wave;
+    int32_t degree;                      /* generic kernel only */
+};
+
+/* Sum-product, decodeCL.c:32-40: out_k = prod_{j != k} x_j, multiplied left to
+ * right in ascending j starting from 1.0f (1*x is exact, so the chain starts at
+ * the first factor).  The prefix x_0..x_{k-1} is shared between outputs. */
+template <int D, int V>
+__device__ __forceinline__ void check_sp(const float (&x)[D][V], float (&out)[D][V])
+{
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        if (D == 1) { out[0][v] = 1.0f; continue; }
+        {
+            float p = x[1][v];
+#pragma unroll
+            for (int j = 2; j < D; ++j) p *= x[j][v];
+            out[0][v] = p;
+        }
+        float pre = x[0][v];
+#pragma unroll
+        for (int k = 1; k < D; ++k) {
+            float p = pre;
+#pragma unroll
+            for (int j = k + 1; j < D; ++j) p *= x[j][v];
+            out[k][v] = p;
+            pre *= x[k][v];
+        }
+    }
+}
+
+/* Min-sum, decodeCL.c:132-146: sign = XOR of (x_j < 0) over j != k, magnitude =
+ * fmin chain over |x_j| starting at 1000.  min is exact and order-free, so the
+ * two-smallest form gives the same floats; NaNs are skipped as fmin skips them. */
+template <int D, int V>
+__device__ __forceinline__ void check_ms(const float (&x)[D][V], float (&out)[D][V])
+{
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        float m1 = 1000.0f, m2 = 1000.0f;
+        int idx = -1;
+        unsigned par = 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const float a = __builtin_fabsf(x[j][v]);
+            par ^= (x[j][v] < 0.0f) ? 1u : 0u;
+            if (a < m1) { m2 = m1; m1 = a; idx = j; }
+            else if (a < m2) { m2 = a; }
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const float b = (k == idx) ? m2 : m1;
+            const unsigned s = par ^ ((x[k][v] < 0.0f) ? 1u : 0u);
+            out[k][v] = s ? -b : b;
+        }
+    }
+}
+
+template <int ALGO, int D, int V>
+__global__ __launch_bounds__(kBlock) void check_kernel(const CheckArgs a)
+{
+    constexpr size_t F = 64 * V;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.y;
+    if (tile_finished<V>(a.done, tile)) return;
+    const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
+    const int r_begin = wave * a.rows_per_wave;
+    const int r_end = min(r_begin + a.rows_per_wave, a.n_rows);
+    const float *Qt = a.Q + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    float *Rt = a.R + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+
+    for (int r = r_begin; r < r_end; ++r) {
+        const int e0 = a.cls_e0[r];
+        float x[D][V], out[D][V];
+#pragma unroll
+        for (int k = 0; k < D; ++k) vload<V>(x[k], Qt + (size_t)(e0 + k) * F);
+        if (ALGO == kAlgoSP) check_sp<D, V>(x, out); else check_ms<D, V>(x, out);
+#pragma unroll
+        for (int k = 0; k < D; ++k) vstore<V>(Rt + (size_t)(e0 + k) * F, out[k]);
+    }
+}
+
+/* Any degree: re-reads the row per output like the reference does (L1/L2 serve
+ * the repeats).  Only used above kMaxUnrolledDegree. */
+template <int ALGO, int V>
+__global__ __launch_bounds__(kBlock) void check_kernel_generic(const CheckArgs a)
+{
+    constexpr size_t F = 64 * V;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.y;
+    if (tile_finished<V>(a.done, tile)) return;
+    const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
+    const int r_begin = wave * a.rows_per_wave;
+    const int r_end = min(r_begin + a.rows_per_wave, a.n_rows);
+    const int D = a.degree;
+    const float *Qt = a.Q + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    float *Rt = a.R + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    for (int r = r_begin; r < r_end; ++r) {
+        const int e0 = a.cls_e0[r];
+        for (int k = 0; k < D; ++k) {
+            float o[V];
+            if (ALGO == kAlgoSP) {
+                float p[V];
+#pragma unroll
+                for (int v = 0; v < V; ++v) p[v] = 1.0f;
+                for (int j = 0; j < D; ++j) {
+                    if (j == k) continue;
+                    float xj[V];
+                    vload<V>(xj, Qt + (size_t)(e0 + j) * F);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) p[v] *= xj[v];
+                }
+#pragma unroll
+                for (int v = 0; v < V; ++v) o[v] = p[v];
+            } else {
+                float b[V];
+                unsigned s[V];
+#pragma unroll
+                for (int v = 0; v < V; ++v) { b[v] = 1000.0f; s[v] = 0; }
+                for (int j = 0; j < D; ++j) {
+                    if (j == k) continue;
+                    float xj[V];
+                    vload<V>(xj, Qt + (size_t)(e0 + j) * F);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        s[v] ^= (xj[v] < 0.0f) ? 1u : 0u;
+                        b[v] = __builtin_fminf(b[v], __builtin_fabsf(xj[v]));
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < V; ++v) o[v] = s[v] ? -b[v] : b[v];
+            }
+            vstore<V>(Rt + (size_t)(e0 + k) * F, o);
+        }
+    }
+}
+
+/* checkResult, decodeCL.c:88-108, on the bit masks: one thread per row XORs the
+ * 64-frame words of its columns (an L2-resident gather), a wave ORs its rows and
+ * issues one atomic per word.  Runs after every variable-node round. */
+struct SyndromeArgs {
+    const int32_t *__restrict__ row_ptr;  /* [M+1] */
+    const int32_t *__restrict__ edge_col; /* [E]   */
+    const uint64_t *__restrict__ hard;    /* [T][N][V] */
+    uint64_t *__restrict__ fail;          /* [T][V] */
+    const uint64_t *__restrict__ done;    /* [T][V] */
+    int32_t M, N;
+};
+
+template <int V> __global__ __launch_bounds__(kBlock) void syndrome_kernel(const SyndromeArgs a)
+{
+    const int tile = blockIdx.y;
+    if (tile_finished<V>(a.done, tile)) return;
+    const int m = blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t *hard_t = a.hard + (size_t)tile * (size_t)a.N * V;
+    uint64_t s[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) s[v] = 0;
+    if (m < a.M) {
+        for (int p = a.row_ptr[m]; p < a.row_ptr[m + 1]; ++p) {
+            const int c = a.edge_col[p];
+#pragma unroll
+            for (int v = 0; v < V; ++v) s[v] ^= hard_t[(size_t)c * V + v];
+        }
+    }
+    /* OR over the wave, one atomic per wave and word */
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        uint64_t x = s[v];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const uint32_t lo = __shfl_xor((uint32_t)x, off);
+            const uint32_t hi = __shfl_xor((uint32_t)(x >> 32), off);
+            x |= ((uint64_t)hi << 32) | lo;
+        }
+        if ((threadIdx.x & 63) == 0 && x)
+            atomicOr(reinterpret_cast<unsigned long long *>(&a.fail[(size_t)tile * V + v]),
+                     (unsigned long long)x);
+    }
+}
+
+/* ========================================================================= */
+/*                              variable node                                 */
+/* ========================================================================= */
+
+struct VarArgs {
+    const float *__restrict__ R;          /* [T][E][F] */
+    float *__restrict__ Q;                /* [T][E][F] */
+    const float *__restrict__ chan;       /* [T][N][F] SP: exp(scale*y); MS: y */
+    uint64_t *hard;                       /* [T][N][V] read-modify-write */
+    const uint64_t *__restrict__ done;    /* [T][V] */
+    const int32_t *__restrict__ cls_col;  /* [n_cols] column ids of this degree class */
+    const int32_t *__restrict__ cls_edge; /* [n_cols][D] edge ids, ascending */
+    int64_t E;
+    int32_t N;
+    int32_t n_cols;
+    int32_t cols_per_wave;
+    int32_t write_q;                      /* 0 on the last round (MyLdpc.cpp:1035-1040) */
+    int32_t degree;                       /* generic kernel only */
+};
+
+/* Sum-product variable node: hardDecision (decodeCL.c:72-82) and refreshQ
+ * (:52-61) share the prefix products.  d[k] is the stored r0-r1 of edge k;
+ * r0 = (1+d)/2, r1 = (1-d)/2 (:39-40; the halving is exact).  t = exp(scale*y),
+ * priors t/(1+t) and 1/(1+t) (:9-11).  Returns q0-q1 per edge in outq and the
+ * full products in full0/full1. */
+template <int D, int V>
+__device__ __forceinline__ void var_sp(const float (&t)[V], const float (&d)[D][V],
+                                       float (&outq)[D][V], float (&full0)[V], float (&full1)[V])
+{
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const float den = 1.0f + t[v];
+        float pre0 = t[v] / den;
+        float pre1 = 1.0f / den;
+        float r0[D], r1[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            r0[k] = (1.0f + d[k][v]) * 0.5f;
+            r1[k] = (1.0f - d[k][v]) * 0.5f;
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            float t0 = pre0, t1 = pre1;
+#pragma unroll
+            for (int j = k + 1; j < D; ++j) { t0 *= r0[j]; t1 *= r1[j]; }
+            const float s = t0 + t1;
+            const float q0 = t0 / s;
+            const float q1 = t1 / s;
+            outq[k][v] = q0 - q1;
+            pre0 *= r0[k];
+            pre1 *= r1[k];
+        }
+        full0[v] = pre0;
+        full1[v] = pre1;
+    }
+}
+
+template <int ALGO, int D, int V>
+__global__ __launch_bounds__(kBlock) void var_kernel(const VarArgs a)
+{
+    constexpr size_t F = 64 * V;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.y;
+    if (tile_finished<V>(a.done, tile)) return;
+    const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
+    const int c_begin = wave * a.cols_per_wave;
+    const int c_end = min(c_begin + a.cols_per_wave, a.n_cols);
+    const float *Rt = a.R + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    float *Qt = a.Q + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    const float *chan_t = a.chan + (size_t)tile * (size_t)a.N * F + (size_t)lane * V;
+    uint64_t *hard_t = a.hard + (size_t)tile * (size_t)a.N * V;
+    uint64_t frozen[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) frozen[v] = a.done[(size_t)tile * V + v];
+
+    for (int ci = c_begin; ci < c_end; ++ci) {
+        const int n = a.cls_col[ci];
+        int e[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) e[k] = a.cls_edge[(size_t)ci * D + k];
+        float ch[V], r[D][V], q[D][V];
+        vload<V>(ch, chan_t + (size_t)n * F);
+#pragma unroll
+        for (int k = 0; k < D; ++k) vload<V>(r[k], Rt + (size_t)e[k] * F);
+        uint64_t old_w[V], new_w[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) old_w[v] = hard_t[(size_t)n * V + v];
+
+        if (ALGO == kAlgoSP) {
+            float f0[V], f1[V];
+            var_sp<D, V>(ch, r, q, f0, f1);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                /* decodeCL.c:78-82: ties and NaN keep the previous bit */
+                const bool oldb = (old_w[v] >> lane) & 1ull;
+                const bool b = (f0[v] > f1[v]) ? false : ((f0[v] < f1[v]) ? true : oldb);
+                new_w[v] = __ballot(b);
+            }
+        } else {
+            /* refreshPostPMS decodeCL.c:157-166, refreshQMS :185 */
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                float p = ch[v];
+#pragma unroll
+                for (int k = 0; k < D; ++k) p += r[k][v];
+#pragma unroll
+                for (int k = 0; k < D; ++k) q[k][v] = p - r[k][v];
+                new_w[v] = __ballot(!(p > 0.0f));
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+                hard_t[(size_t)n * V + v] = (old_w[v] & frozen[v]) | (new_w[v] & ~frozen[v]);
+        }
+        if (a.write_q) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) vstore<V>(Qt + (size_t)e[k] * F, q[k]);
+        }
+    }
+}
+
+template <int ALGO, int V>
+__global__ __launch_bounds__(kBlock) void var_kernel_generic(const VarArgs a)
+{
+    constexpr size_t F = 64 * V;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.y;
+    if (tile_finished<V>(a.done, tile)) return;
+    const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
+    const int c_begin = wave * a.cols_per_wave;
+    const int c_end = min(c_begin + a.cols_per_wave, a.n_cols);
+    const int D = a.degree;
+    const float *Rt = a.R + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    float *Qt = a.Q + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    const float *chan_t = a.chan + (size_t)tile * (size_t)a.N * F + (size_t)lane * V;
+    uint64_t *hard_t = a.hard + (size_t)tile * (size_t)a.N * V;
+    uint64_t frozen[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) frozen[v] = a.done[(size_t)tile * V + v];
+
+    for (int ci = c_begin; ci < c_end; ++ci) {
+        const int n = a.cls_col[ci];
+        const int32_t *e = a.cls_edge + (size_t)ci * D;
+        float ch[V];
+        vload<V>(ch, chan_t + (size_t)n * F);
+        uint64_t old_w[V], new_w[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) old_w[v] = hard_t[(size_t)n * V + v];
+        if (ALGO == kAlgoSP) {
+            float p0[V], p1[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const float den = 1.0f + ch[v];
+                p0[v] = ch[v] / den;
+                p1[v] = 1.0f / den;
+            }
+            for (int k = 0; k <= D; ++k) {     /* k == D: the full product (hard decision) */
+                float t0[V], t1[V];
+#pragma unroll
+                for (int v = 0; v < V; ++v) { t0[v] = p0[v]; t1[v] = p1[v]; }
+                for (int j = 0; j < D; ++j) {
+                    if (j == k) continue;
+                    float dj[V];
+                    vload<V>(dj, Rt + (size_t)e[j] * F);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        t0[v] *= (1.0f + dj[v]) * 0.5f;
+                        t1[v] *= (1.0f - dj[v]) * 0.5f;
+                    }
+                }
+                if (k < D) {
+                    if (a.write_q) {
+                        float o[V];
+#pragma unroll
+                        for (int v = 0; v < V; ++v) {
+                            const float s = t0[v] + t1[v];
+                            o[v] = t0[v] / s - t1[v] / s;
+                        }
+                        vstore<V>(Qt + (size_t)e[k] * F, o);
+                    }
+                } else {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        const bool oldb = (old_w[v] >> lane) & 1ull;
+                        const bool b = (t0[v] > t1[v]) ? false : ((t0[v] < t1[v]) ? true : oldb);
+                        new_w[v] = __ballot(b);
+                    }
+                }
+            }
+        } else {
+            float p[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) p[v] = ch[v];
+            for (int j = 0; j < D; ++j) {
+                float rj[V];
+                vload<V>(rj, Rt + (size_t)e[j] * F);
+#pragma unroll
+                for (int v = 0; v < V; ++v) p[v] += rj[v];
+            }
+#pragma unroll
+            for (int v = 0; v < V; ++v) new_w[v] = __ballot(!(p[v] > 0.0f));
+            if (a.write_q) {
+                for (int j = 0; j < D; ++j) {
+                    float rj[V], o[V];
+                    vload<V>(rj, Rt + (size_t)e[j] * F);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) o[v] = p[v] - rj[v];
+                    vstore<V>(Qt + (size_t)e[j] * F, o);
+                }
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+                hard_t[(size_t)n * V + v] = (old_w[v] & frozen[v]) | (new_w[v] & ~frozen[v]);
+        }
+    }
+}
+
+/* ========================================================================= */
+/*                        init / bookkeeping / pack                           */
+/* ========================================================================= */
+
+struct InitArgs {
+    const float *__restrict__ llr;        /* [frames][N] frame-major (reference layout) */
+    float *__restrict__ chan;             /* [T][N][F] */
+    float *__restrict__ Q;                /* [T][E][F] */
+    uint64_t *__restrict__ hard;          /* [T][N][V] */
+    const int32_t *__restrict__ col_ptr;  /* [N+1] */
+    const int32_t *__restrict__ col_edge; /* [E] */
+    int64_t E;
+    int64_t frames;
+    int32_t N;
+    float llr_scale;
+};
+
+/* decodeInit (decodeCL.c:3-22) / decodeInitMS (:113-124) + the transpose from the
+ * reference's frame-major input to the tile layout.  One block = 32 columns x one
+ * tile; the patch crosses LDS so both the read (along n) and the writes (along
+ * frames) are contiguous.  Frames past `frames` are filled with y = +1. */
+constexpr int kInitCols = 32;
+
+template <int ALGO, int V>
+__global__ __launch_bounds__(kBlock) void init_kernel(const InitArgs a)
+{
+    constexpr int F = 64 * V;
+    constexpr int LD = F + 1;             /* +1 float: conflict-free column writes */
+    __shared__ float patch[kInitCols * LD];
+    const int tile = blockIdx.y;
+    const int n0 = blockIdx.x * kInitCols;
+    {
+        const int c = threadIdx.x & (kInitCols - 1);
+        const int n = n0 + c;
+        for (int f = threadIdx.x / kInitCols; f < F; f += kBlock / kInitCols) {
+            const int64_t frame = (int64_t)tile * F + f;
+            float y = 1.0f;
+            if (frame < a.frames && n < a.N) y = a.llr[(size_t)frame * a.N + n];
+            patch[c * LD + f] = y;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int c = threadIdx.x >> 6; c < kInitCols; c += kWavesPerBlock) {
+        const int n = n0 + c;
+        if (n >= a.N) break;
+        float ch[V], q[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float y = patch[c * LD + lane * V + v];
+            if (ALGO == kAlgoSP) {
+                const float t = ldpc_expf(a.llr_scale * y);         /* decodeCL.c:9 */
+                ch[v] = t;
+                q[v] = t / (1.0f + t) - 1.0f / (1.0f + t);          /* :10-11, as q0-q1 */
+            } else {
+                ch[v] = y;
+                q[v] = y;                                           /* :121 */
+            }
+        }
+        vstore<V>(a.chan + ((size_t)tile * a.N + n) * F + (size_t)lane * V, ch);
+        for (int p = a.col_ptr[n]; p < a.col_ptr[n + 1]; ++p)
+            vstore<V>(a.Q + ((size_t)tile * (size_t)a.E + (size_t)a.col_edge[p]) * F + (size_t)lane * V, q);
+        if (lane < V) a.hard[((size_t)tile * a.N + n) * V + lane] = 0;
+    }
+}
+
+struct StateArgs {
+    uint64_t *__restrict__ done;        /* [T][V] */
+    const uint64_t *__restrict__ fail;  /* [T][V] syndrome of round `iter` */
+    int32_t *__restrict__ iters;        /* [T][F] */
+    int32_t *__restrict__ active;       /* [1] set to 1 if any frame is still running */
+    int64_t frames;
+    int32_t iter;                       /* round whose syndrome `fail` holds; 0 = initialise */
+    int32_t max_iter;
+    int32_t freeze;                     /* early_term */
+};
+
+/* isDones bookkeeping (decodeCL.c:48-49, checkDones :296-300): a frame whose
+ * syndrome is clean after round `iter` is frozen with iters = iter.
+ * iter == 0 initialises: padding frames are born frozen, iters = max_iter. */
+template <int V> __global__ void state_kernel(const StateArgs a)
+{
+    constexpr int F = 64 * V;
+    const int tile = blockIdx.x;
+    const int lane = threadIdx.x;      /* 64 threads */
+    bool any_active = false;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int64_t frame = (int64_t)tile * F + (int64_t)lane * V + v;
+        const bool valid = frame < a.frames;
+        uint64_t d;
+        if (a.iter == 0) {
+            d = __ballot(!valid);
+            a.iters[(size_t)tile * F + lane * V + v] = a.max_iter;
+        } else {
+            const uint64_t old = a.done[(size_t)tile * V + v];
+            const uint64_t clean = ~a.fail[(size_t)tile * V + v];
+            const uint64_t newly = clean & ~old;
+            if ((newly >> lane) & 1ull) a.iters[(size_t)tile * F + lane * V + v] = a.iter;
+            d = a.freeze ? (old | clean) : old;
+        }
+        if (lane == 0) a.done[(size_t)tile * V + v] = d;
+        any_active = any_active || (d != ~0ull);
+    }
+    if (lane == 0 && any_active && a.active) atomicOr(a.active, 1);
+}
+
+struct PackArgs {
+    const uint64_t *__restrict__ hard;  /* [T][N][V] */
+    uint8_t *__restrict__ out;
+    const int32_t *__restrict__ iters_tile; /* [T][F] */
+    int32_t *__restrict__ iters_out;    /* [frames] or nullptr */
+    int64_t frames;
+    int64_t out_bytes;
+    int32_t N, K;
+    int32_t pack_mode;
+};
+
+/* toChar, decodeCL.c:188-199: byte j of frame b = hard bits 8j..8j+7, LSB first,
+ * at (b*K)/8 + j.  pack_mode 1 = decodeCPU's bit packing at bit b*K+i
+ * (MyLdpc.cpp:765-774).  One thread per output byte, lanes along j. */
+template <int V> __global__ __launch_bounds__(kBlock) void pack_kernel(const PackArgs a)
+{
+    constexpr int F = 64 * V;
+    if (a.pack_mode == 0) {
+        const int64_t frame = blockIdx.x;
+        const int j = blockIdx.y * kBlock + threadIdx.x;
+        if (j == 0 && a.iters_out) {
+            a.iters_out[frame] = a.iters_tile[frame];   /* tile-major index == frame index */
+        }
+        if (j >= a.K / 8) return;
+        const int64_t tile = frame / F;
+        const int fi = (int)(frame % F);
+        const int l = fi / V, v = fi % V;
+        const uint64_t *h = a.hard + ((size_t)tile * a.N + (size_t)j * 8) * V + v;
+        unsigned byte = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) byte |= (unsigned)((h[(size_t)b * V] >> l) & 1ull) << b;
+        const int64_t off = frame * (int64_t)a.K / 8 + j;
+        if (off < a.out_bytes) a.out[off] = (uint8_t)byte;
+    } else {
+        const int64_t ob = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        if (ob < a.frames && a.iters_out) a.iters_out[ob] = a.iters_tile[ob];
+        if (ob >= a.out_bytes) return;
+        unsigned byte = 0;
+        for (int b = 0; b < 8; ++b) {
+            const int64_t bit = ob * 8 + b;
+            const int64_t frame = bit / a.K;
+            if (frame >= a.frames) break;
+            const int i = (int)(bit % a.K);
+            const int64_t tile = frame / F;
+            const int fi = (int)(frame % F);
+            const uint64_t w = a.hard[((size_t)tile * a.N + i) * V + (fi % V)];
+            byte |= (unsigned)((w >> (fi / V)) & 1ull) << b;
+        }
+        a.out[ob] = (uint8_t)byte;
+    }
+}
+
+}  // namespace ldpc

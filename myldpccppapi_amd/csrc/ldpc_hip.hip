@@ -1,0 +1,740 @@
+/*
+ * ldpc_hip.hip -- host side of libldpc_hip.so (C ABI in include/ldpc_hip.h).
+ *
+ * Owns the HBM-resident decoder state, builds the per-degree work lists from
+ * the edge list, and drives the flooding rounds the way the reference's host
+ * loops do (decodeOnceSP MyLdpc.cpp:977-1059, decodeOnceMS :786-848) -- minus
+ * the per-kernel queue.finish() and the blocking flags read-back every
+ * iteration (:1024-1034): frames freeze on the device (state_kernel) and the
+ * host only polls an "anything still running" word every poll_interval rounds.
+ *
+ * Round i (1-based), for every tile of F = 64*V frames:
+ *   check_i    : R_i = check(Q_{i-1})
+ *   var_i      : bits_i = hard(R_i) (frozen frames keep theirs); Q_i = var(R_i)
+ *   syndrome_i : fail_i = any parity check of bits_i odd          } early_term only
+ *   state_i    : frames with clean bits_i freeze, iters = i        } (and after the last round)
+ * then pack.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ldpc_hip.h"
+#include "flood_kernels.hpp"
+#include "layered_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(LDPC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                           \
+    } while (0)
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count)
+    {
+        release();
+        n = count;
+        if (!count) return hipSuccess;
+        return hipMalloc((void **)&p, count * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T> &h)
+    {
+        hipError_t e = alloc(h.size());
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+}  // namespace
+
+/* ------------------------------------------------------------------ graph */
+
+struct ldpc_graph {
+    int32_t M = 0, N = 0;
+    int64_t E = 0;
+    std::vector<int32_t> rows, cols;        /* [E] hRows, hCols           */
+    std::vector<int32_t> row_ptr;           /* [M+1] hRowRange            */
+    std::vector<int32_t> col_ptr, col_edge; /* CSC, edges ascending       */
+    int32_t max_row_deg = 0, max_col_deg = 0;
+};
+
+/* ---------------------------------------------------------------- decoder */
+
+namespace {
+
+using CheckFn = void (*)(const ldpc::CheckArgs);
+using VarFn = void (*)(const ldpc::VarArgs);
+
+template <int ALGO, int V, int D> struct FloodTable {
+    static void fill(CheckFn *c, VarFn *v)
+    {
+        c[D] = ldpc::check_kernel<ALGO, D, V>;
+        v[D] = ldpc::var_kernel<ALGO, D, V>;
+        FloodTable<ALGO, V, D - 1>::fill(c, v);
+    }
+};
+template <int ALGO, int V> struct FloodTable<ALGO, V, 0> {
+    static void fill(CheckFn *c, VarFn *v)
+    {
+        c[0] = ldpc::check_kernel_generic<ALGO, V>;
+        v[0] = ldpc::var_kernel_generic<ALGO, V>;
+    }
+};
+
+struct RowClass {
+    int degree = 0;
+    int count = 0;
+    DevBuf<int32_t> e0;
+};
+struct ColClass {
+    int degree = 0;
+    int count = 0;
+    DevBuf<int32_t> col, edge;
+};
+
+struct TimedSpan {
+    hipEvent_t a, b;
+    int kind; /* 0 check, 1 var, 2 other */
+};
+
+}  // namespace
+
+struct ldpc_decoder {
+    ldpc_decoder_config cfg{};
+    int32_t M = 0, N = 0;
+    int64_t E = 0;
+    int V = 1, F = 64, T = 0; /* frames per lane, per tile, tiles at max_batch */
+    std::vector<int32_t> h_col_ptr, h_col_edge, h_rows, h_cols;
+
+    DevBuf<int32_t> row_ptr, edge_col, col_ptr, col_edge;
+    DevBuf<float> chan, Q, R;
+    DevBuf<uint64_t> hard, failw, done;
+    DevBuf<int32_t> iters, active;
+    std::vector<RowClass> row_classes;
+    std::vector<ColClass> col_classes;
+    CheckFn check_fn[ldpc::kMaxUnrolledDegree + 1] = {};
+    VarFn var_fn[ldpc::kMaxUnrolledDegree + 1] = {};
+
+    ldpc::LayeredPlan layered;          /* LDPC_ALGO_LAYERED */
+
+    /* staging for the host-buffer entry point */
+    hipStream_t stream = nullptr;
+    DevBuf<float> llr_stage;
+    DevBuf<uint8_t> out_stage;
+    DevBuf<int32_t> iters_stage;
+    int32_t *h_active = nullptr;        /* pinned */
+
+    bool timing = false;
+    std::vector<TimedSpan> spans;
+    size_t spans_used = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
+    int32_t tap_iter = 0;
+    int tune_rpw = 0, tune_cpw = 0;     /* LDPC_TUNE_RPW / LDPC_TUNE_CPW: rows / columns per wave */
+    int32_t last_iterations = 0;
+    int64_t last_frames = 0;
+    DevBuf<int32_t> summary;            /* [2]: max iters, converged count */
+
+    ~ldpc_decoder()
+    {
+        for (auto &s : spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+        if (ev_begin) (void)hipEventDestroy(ev_begin);
+        if (ev_end) (void)hipEventDestroy(ev_end);
+        if (h_active) (void)hipHostFree(h_active);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+/* summary[0] = max over frames of iters (the reference's `Time=`), summary[1] =
+ * number of frames whose syndrome ended clean. */
+template <int V>
+__global__ void summary_kernel(const int32_t *iters, const uint64_t *done, const uint64_t *fail,
+                               int64_t frames, int32_t freeze, int32_t *summary)
+{
+    constexpr int F = 64 * V;
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= frames) return;
+    const int64_t tile = f / F;
+    const int fi = (int)(f % F);
+    const int l = fi / V, v = fi % V;
+    atomicMax(&summary[0], iters[f]);
+    const uint64_t ok = freeze ? done[tile * V + v] : ~fail[tile * V + v];
+    if ((ok >> l) & 1ull) atomicAdd(&summary[1], 1);
+}
+
+int pick_frames_per_lane(const ldpc_decoder_config &cfg, int32_t max_deg)
+{
+    if (cfg.frames_per_lane) return cfg.frames_per_lane;
+    /* wide tiles (16 B per lane) once there are enough frames to fill them and
+     * the register arrays of the unrolled kernels stay moderate */
+    if (cfg.max_batch >= 1024 && max_deg <= 8) return 4;
+    if (cfg.max_batch >= 256 && max_deg <= ldpc::kMaxUnrolledDegree) return 2;
+    return 1;
+}
+
+hipError_t span_begin(ldpc_decoder *d, hipStream_t s, int kind)
+{
+    if (!d->timing) return hipSuccess;
+    if (d->spans_used == d->spans.size()) {
+        TimedSpan t{};
+        hipError_t e = hipEventCreate(&t.a);
+        if (e != hipSuccess) return e;
+        e = hipEventCreate(&t.b);
+        if (e != hipSuccess) return e;
+        d->spans.push_back(t);
+    }
+    d->spans[d->spans_used].kind = kind;
+    return hipEventRecord(d->spans[d->spans_used].a, s);
+}
+
+hipError_t span_end(ldpc_decoder *d, hipStream_t s)
+{
+    if (!d->timing) return hipSuccess;
+    return hipEventRecord(d->spans[d->spans_used++].b, s);
+}
+
+template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t frames,
+                                  uint8_t *out_dev, int64_t out_bytes, int32_t *iters_dev,
+                                  hipStream_t s)
+{
+    using namespace ldpc;
+    const bool sp = d->cfg.algo == LDPC_ALGO_SP;
+    const int F = 64 * V;
+    const int tiles = (int)((frames + F - 1) / F);
+    const int max_iter = d->cfg.max_iter;
+    const int rounds = d->tap_iter ? std::min(d->tap_iter, max_iter) : max_iter;
+    const bool freeze = d->cfg.early_term != 0;
+    const size_t slot = (size_t)d->T * V;   /* words per fail slot */
+
+    HIP_TRY(hipMemsetAsync(d->failw.p, 0, d->failw.n * sizeof(uint64_t), s));
+    HIP_TRY(hipMemsetAsync(d->summary.p, 0, 2 * sizeof(int32_t), s));
+
+    HIP_TRY(span_begin(d, s, 2));
+    {
+        InitArgs a{llr_dev, d->chan.p, d->Q.p, d->hard.p, d->col_ptr.p, d->col_edge.p,
+                   d->E, frames, d->N, d->cfg.llr_scale};
+        dim3 grid((d->N + kInitCols - 1) / kInitCols, tiles);
+        if (sp) init_kernel<kAlgoSP, V><<<grid, kBlock, 0, s>>>(a);
+        else init_kernel<kAlgoMS, V><<<grid, kBlock, 0, s>>>(a);
+        StateArgs st{d->done.p, nullptr, d->iters.p, nullptr, frames, 0, max_iter, freeze ? 1 : 0};
+        state_kernel<V><<<tiles, 64, 0, s>>>(st);
+    }
+    HIP_TRY(span_end(d, s));
+
+    int launched = 0;
+    for (int it = 1; it <= rounds; ++it) {
+        /* check_i: R_i = check(Q_{i-1}) */
+        HIP_TRY(span_begin(d, s, 0));
+        for (auto &rc : d->row_classes) {
+            CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree};
+            const int rpw = d->tune_rpw ? d->tune_rpw : 2;
+            a.rows_per_wave = rpw;
+            const int waves = (rc.count + rpw - 1) / rpw;
+            dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
+            const int slotk = rc.degree <= kMaxUnrolledDegree ? rc.degree : 0;
+            d->check_fn[slotk]<<<grid, kBlock, 0, s>>>(a);
+        }
+        HIP_TRY(span_end(d, s));
+        /* var_i: bits_i = hard(R_i); Q_i = var(R_i) unless this is the last round */
+        HIP_TRY(span_begin(d, s, 1));
+        for (auto &cc : d->col_classes) {
+            VarArgs a{d->R.p, d->Q.p, d->chan.p, d->hard.p, d->done.p, cc.col.p, cc.edge.p,
+                      d->E, d->N, cc.count, 1, (it < max_iter) ? 1 : 0, cc.degree};
+            const int cpw = d->tune_cpw ? d->tune_cpw : 2;
+            a.cols_per_wave = cpw;
+            const int waves = (cc.count + cpw - 1) / cpw;
+            dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
+            const int slotk = cc.degree <= kMaxUnrolledDegree ? cc.degree : 0;
+            d->var_fn[slotk]<<<grid, kBlock, 0, s>>>(a);
+        }
+        HIP_TRY(span_end(d, s));
+        launched = it;
+        /* syndrome of bits_i, then freeze the frames that are clean (iters = i) */
+        if (freeze || it == rounds) {
+            HIP_TRY(span_begin(d, s, 2));
+            uint64_t *fw = d->failw.p + (size_t)it * slot;
+            SyndromeArgs sa{d->row_ptr.p, d->edge_col.p, d->hard.p, fw, d->done.p, d->M, d->N};
+            dim3 sgrid((d->M + kBlock - 1) / kBlock, tiles);
+            syndrome_kernel<V><<<sgrid, kBlock, 0, s>>>(sa);
+            StateArgs st{d->done.p, fw, d->iters.p, nullptr, frames, it, max_iter, 1};
+            const bool poll = freeze && it < rounds && d->cfg.poll_interval > 0 &&
+                              (it % d->cfg.poll_interval) == 0;
+            if (poll) {
+                HIP_TRY(hipMemsetAsync(d->active.p, 0, sizeof(int32_t), s));
+                st.active = d->active.p;
+            }
+            state_kernel<V><<<tiles, 64, 0, s>>>(st);
+            HIP_TRY(span_end(d, s));
+            if (poll) {
+                HIP_TRY(hipMemcpyAsync(d->h_active, d->active.p, sizeof(int32_t),
+                                       hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                if (*d->h_active == 0) break;   /* every frame frozen: MyLdpc.cpp:1035-1036 */
+            }
+        }
+    }
+    d->last_iterations = launched;
+
+    HIP_TRY(span_begin(d, s, 2));
+    {
+        PackArgs pa{d->hard.p, out_dev, d->iters.p, iters_dev, frames, out_bytes, d->N, d->cfg.K,
+                    d->cfg.pack_mode};
+        if (d->cfg.pack_mode == LDPC_PACK_BYTES) {
+            const int kb = d->cfg.K / 8;
+            dim3 grid((unsigned)frames, (kb + kBlock - 1) / kBlock);
+            if (out_dev && frames) pack_kernel<V><<<grid, kBlock, 0, s>>>(pa);
+        } else {
+            const int64_t n = std::max<int64_t>(out_bytes, frames);
+            dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+            if (out_dev && frames) pack_kernel<V><<<grid, kBlock, 0, s>>>(pa);
+        }
+        /* after the final state_kernel `done` marks exactly the converged frames */
+        summary_kernel<V><<<(unsigned)((frames + 255) / 256), 256, 0, s>>>(
+            d->iters.p, d->done.p, d->failw.p, frames, 1, d->summary.p);
+    }
+    HIP_TRY(span_end(d, s));
+    HIP_TRY(hipGetLastError());
+    return LDPC_OK;
+}
+
+int build_classes(ldpc_decoder *d, const ldpc_graph *g)
+{
+    std::map<int, std::vector<int32_t>> rows_by_deg, cols_by_deg;
+    for (int32_t m = 0; m < g->M; ++m) {
+        const int deg = g->row_ptr[m + 1] - g->row_ptr[m];
+        if (deg > 0) rows_by_deg[deg].push_back(g->row_ptr[m]);
+    }
+    for (int32_t n = 0; n < g->N; ++n) {
+        const int deg = g->col_ptr[n + 1] - g->col_ptr[n];
+        cols_by_deg[deg].push_back(n);   /* degree 0: still needs its hard bit */
+    }
+    d->row_classes.resize(rows_by_deg.size());
+    size_t i = 0;
+    for (auto &kv : rows_by_deg) {
+        RowClass &rc = d->row_classes[i++];
+        rc.degree = kv.first;
+        rc.count = (int)kv.second.size();
+        HIP_TRY(rc.e0.upload(kv.second));
+    }
+    d->col_classes.resize(cols_by_deg.size());
+    i = 0;
+    for (auto &kv : cols_by_deg) {
+        ColClass &cc = d->col_classes[i++];
+        cc.degree = kv.first;
+        cc.count = (int)kv.second.size();
+        std::vector<int32_t> edges;
+        edges.reserve((size_t)cc.count * std::max(cc.degree, 1));
+        for (int32_t n : kv.second)
+            for (int32_t p = g->col_ptr[n]; p < g->col_ptr[n + 1]; ++p) edges.push_back(g->col_edge[p]);
+        if (edges.empty()) edges.push_back(0);
+        HIP_TRY(cc.col.upload(kv.second));
+        HIP_TRY(cc.edge.upload(edges));
+    }
+    return LDPC_OK;
+}
+
+}  // namespace
+
+/* ================================================================== C ABI */
+
+extern "C" {
+
+int ldpc_abi_version(void) { return LDPC_HIP_ABI_VERSION; }
+
+const char *ldpc_last_error(void) { return g_err.c_str(); }
+
+int ldpc_device_count(int *count)
+{
+    if (!count) return fail(LDPC_ERR_ARG, "count is NULL");
+    *count = 0;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(LDPC_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    *count = n;
+    return LDPC_OK;
+}
+
+int64_t ldpc_out_bytes(int32_t K, int64_t frames, int32_t pack_mode)
+{
+    if (frames <= 0 || K <= 0) return 0;
+    if (pack_mode == LDPC_PACK_BYTES) return (frames - 1) * (int64_t)K / 8 + K / 8;
+    return (frames * (int64_t)K + 7) / 8;
+}
+
+int ldpc_graph_create(const int32_t *rows, const int32_t *cols, int64_t E, int32_t M, int32_t N,
+                      ldpc_graph **out)
+{
+    if (!out) return fail(LDPC_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!rows || !cols) return fail(LDPC_ERR_ARG, "rows/cols is NULL");
+    if (M <= 0 || N <= 0 || E <= 0) return fail(LDPC_ERR_ARG, "M, N, E must be positive");
+    if (E > 0x7fffffffLL) return fail(LDPC_ERR_ARG, "E does not fit int32 edge ids");
+    for (int64_t e = 0; e < E; ++e) {
+        if (rows[e] < 0 || rows[e] >= M || cols[e] < 0 || cols[e] >= N)
+            return fail(LDPC_ERR_ARG, "edge %lld = (%d, %d) outside %d x %d", (long long)e, rows[e],
+                        cols[e], M, N);
+        if (e && (rows[e] < rows[e - 1] || (rows[e] == rows[e - 1] && cols[e] <= cols[e - 1])))
+            return fail(LDPC_ERR_ARG, "edges must be in strictly ascending row-major order (edge %lld)",
+                        (long long)e);
+    }
+    ldpc_graph *g = new (std::nothrow) ldpc_graph;
+    if (!g) return fail(LDPC_ERR_NOMEM, "out of memory");
+    g->M = M; g->N = N; g->E = E;
+    g->rows.assign(rows, rows + E);
+    g->cols.assign(cols, cols + E);
+    g->row_ptr.assign((size_t)M + 1, 0);
+    g->col_ptr.assign((size_t)N + 1, 0);
+    for (int64_t e = 0; e < E; ++e) { ++g->row_ptr[rows[e] + 1]; ++g->col_ptr[cols[e] + 1]; }
+    for (int32_t m = 0; m < M; ++m) {
+        g->max_row_deg = std::max(g->max_row_deg, g->row_ptr[m + 1]);
+        g->row_ptr[m + 1] += g->row_ptr[m];
+    }
+    for (int32_t n = 0; n < N; ++n) {
+        g->max_col_deg = std::max(g->max_col_deg, g->col_ptr[n + 1]);
+        g->col_ptr[n + 1] += g->col_ptr[n];
+    }
+    /* column lists in ascending edge id, as the reference's linked lists are
+     * appended in edge order (MyLdpc.cpp:209-218) */
+    g->col_edge.assign((size_t)E, 0);
+    std::vector<int32_t> fill(g->col_ptr.begin(), g->col_ptr.end() - 1);
+    for (int64_t e = 0; e < E; ++e) g->col_edge[fill[cols[e]]++] = (int32_t)e;
+    *out = g;
+    return LDPC_OK;
+}
+
+int ldpc_graph_destroy(ldpc_graph *g)
+{
+    delete g;
+    return LDPC_OK;
+}
+
+int ldpc_graph_info(const ldpc_graph *g, int32_t *M, int32_t *N, int64_t *E, int32_t *max_row_deg,
+                    int32_t *max_col_deg)
+{
+    if (!g) return fail(LDPC_ERR_ARG, "graph is NULL");
+    if (M) *M = g->M;
+    if (N) *N = g->N;
+    if (E) *E = g->E;
+    if (max_row_deg) *max_row_deg = g->max_row_deg;
+    if (max_col_deg) *max_col_deg = g->max_col_deg;
+    return LDPC_OK;
+}
+
+void ldpc_decoder_config_init(ldpc_decoder_config *cfg)
+{
+    if (!cfg) return;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->struct_size = sizeof *cfg;
+    cfg->max_batch = 1;
+    cfg->algo = LDPC_ALGO_SP;
+    cfg->msg_dtype = LDPC_MSG_F32;
+    cfg->max_iter = 40;       /* MyLdpc.cpp:24 */
+    cfg->llr_scale = 8.0f;    /* decodeCL.c:9 */
+    cfg->early_term = 1;
+    cfg->pack_mode = LDPC_PACK_BYTES;
+}
+
+int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldpc_decoder **out)
+{
+    if (!out) return fail(LDPC_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!g || !cfg) return fail(LDPC_ERR_ARG, "graph/config is NULL");
+    if (cfg->struct_size != sizeof(ldpc_decoder_config))
+        return fail(LDPC_ERR_ARG, "config struct_size %u != %zu (ABI mismatch)", cfg->struct_size,
+                    sizeof(ldpc_decoder_config));
+    if (cfg->K <= 0 || cfg->K > g->N) return fail(LDPC_ERR_ARG, "K=%d out of range", cfg->K);
+    if (cfg->max_batch <= 0) return fail(LDPC_ERR_ARG, "max_batch must be positive");
+    if (cfg->max_iter <= 0 || cfg->max_iter > 100000) return fail(LDPC_ERR_ARG, "max_iter out of range");
+    if (cfg->algo != LDPC_ALGO_SP && cfg->algo != LDPC_ALGO_MS && cfg->algo != LDPC_ALGO_LAYERED)
+        return fail(LDPC_ERR_ARG, "unknown algo %d", cfg->algo);
+    if (cfg->pack_mode != LDPC_PACK_BYTES && cfg->pack_mode != LDPC_PACK_BITS)
+        return fail(LDPC_ERR_ARG, "unknown pack_mode %d", cfg->pack_mode);
+    if (cfg->frames_per_lane != 0 && cfg->frames_per_lane != 1 && cfg->frames_per_lane != 2 &&
+        cfg->frames_per_lane != 4)
+        return fail(LDPC_ERR_ARG, "frames_per_lane must be 0, 1, 2 or 4");
+    if (cfg->msg_dtype != LDPC_MSG_F32)
+        return fail(LDPC_ERR_UNSUPPORTED, "msg_dtype %d: only fp32 messages are built so far",
+                    cfg->msg_dtype);
+    for (int i = 0; i < 8; ++i)
+        if (cfg->reserved[i]) return fail(LDPC_ERR_ARG, "reserved config fields must be 0");
+
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(LDPC_ERR_HIP, "device %d not present (%d HIP devices)", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    ldpc_decoder *d = new (std::nothrow) ldpc_decoder;
+    if (!d) return fail(LDPC_ERR_NOMEM, "out of memory");
+    std::unique_ptr<ldpc_decoder> guard(d);
+    d->cfg = *cfg;
+    d->M = g->M; d->N = g->N; d->E = g->E;
+    d->h_col_ptr = g->col_ptr; d->h_col_edge = g->col_edge; d->h_rows = g->rows; d->h_cols = g->cols;
+    const int32_t max_deg = std::max(g->max_row_deg, g->max_col_deg);
+    if (const char *e = getenv("LDPC_TUNE_RPW")) d->tune_rpw = atoi(e);
+    if (const char *e = getenv("LDPC_TUNE_CPW")) d->tune_cpw = atoi(e);
+    d->V = pick_frames_per_lane(*cfg, max_deg);
+    d->F = 64 * d->V;
+    d->T = (cfg->max_batch + d->F - 1) / d->F;
+
+    HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&d->ev_begin));
+    HIP_TRY(hipEventCreate(&d->ev_end));
+    HIP_TRY(hipHostMalloc((void **)&d->h_active, sizeof(int32_t), hipHostMallocDefault));
+    HIP_TRY(d->row_ptr.upload(g->row_ptr));
+    HIP_TRY(d->edge_col.upload(g->cols));
+    HIP_TRY(d->col_ptr.upload(g->col_ptr));
+    HIP_TRY(d->col_edge.upload(g->col_edge));
+    const size_t TF = (size_t)d->T * d->F;
+    HIP_TRY(d->hard.alloc((size_t)d->T * d->N * d->V));
+    HIP_TRY(d->failw.alloc((size_t)(cfg->max_iter + 2) * d->T * d->V));
+    HIP_TRY(d->done.alloc((size_t)d->T * d->V));
+    HIP_TRY(d->iters.alloc(TF));
+    HIP_TRY(d->active.alloc(1));
+    HIP_TRY(d->summary.alloc(2));
+
+    if (cfg->algo == LDPC_ALGO_LAYERED) {
+        int rc = ldpc::layered_plan_create(&d->layered, g->M, g->N, g->E, g->row_ptr, g->cols,
+                                           cfg->layer_rows, d->T, d->V);
+        if (rc == -1) return fail(LDPC_ERR_ARG, "layer_rows=%d must divide M=%d and rows of a layer "
+                                  "must not share a column", cfg->layer_rows, g->M);
+        if (rc) return fail(LDPC_ERR_HIP, "layered plan allocation failed: %s",
+                            hipGetErrorString(hipGetLastError()));
+    } else {
+        HIP_TRY(d->chan.alloc(TF * d->N));
+        HIP_TRY(d->Q.alloc(TF * (size_t)d->E));
+        HIP_TRY(d->R.alloc(TF * (size_t)d->E));
+        int rc = build_classes(d, g);
+        if (rc) return rc;
+        const bool sp = cfg->algo == LDPC_ALGO_SP;
+        constexpr int DM = ldpc::kMaxUnrolledDegree;
+        if (sp) {
+            if (d->V == 1) FloodTable<ldpc::kAlgoSP, 1, DM>::fill(d->check_fn, d->var_fn);
+            else if (d->V == 2) FloodTable<ldpc::kAlgoSP, 2, DM>::fill(d->check_fn, d->var_fn);
+            else FloodTable<ldpc::kAlgoSP, 4, DM>::fill(d->check_fn, d->var_fn);
+        } else {
+            if (d->V == 1) FloodTable<ldpc::kAlgoMS, 1, DM>::fill(d->check_fn, d->var_fn);
+            else if (d->V == 2) FloodTable<ldpc::kAlgoMS, 2, DM>::fill(d->check_fn, d->var_fn);
+            else FloodTable<ldpc::kAlgoMS, 4, DM>::fill(d->check_fn, d->var_fn);
+        }
+    }
+    *out = guard.release();
+    return LDPC_OK;
+}
+
+int ldpc_decoder_destroy(ldpc_decoder *d)
+{
+    if (!d) return LDPC_OK;
+    (void)hipSetDevice(d->cfg.device);
+    (void)hipDeviceSynchronize();
+    ldpc::layered_plan_destroy(&d->layered);
+    delete d;
+    return LDPC_OK;
+}
+
+int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, uint8_t *out_dev,
+                       int64_t out_bytes, int32_t *iters_dev, void *stream)
+{
+    if (!d) return fail(LDPC_ERR_ARG, "decoder is NULL");
+    if (frames < 0 || frames > d->cfg.max_batch)
+        return fail(LDPC_ERR_ARG, "frames=%lld outside [0, max_batch=%d]", (long long)frames,
+                    d->cfg.max_batch);
+    if (frames == 0) { d->last_frames = 0; d->have_last = false; return LDPC_OK; }
+    if (!llr_dev) return fail(LDPC_ERR_ARG, "llr is NULL");
+    const int64_t need = ldpc_out_bytes(d->cfg.K, frames, d->cfg.pack_mode);
+    if (out_dev && out_bytes < need && d->cfg.pack_mode == LDPC_PACK_BITS)
+        return fail(LDPC_ERR_ARG, "out_bytes=%lld < %lld", (long long)out_bytes, (long long)need);
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    d->spans_used = 0;
+    d->last_stream = s;
+    d->last_frames = frames;
+    HIP_TRY(hipEventRecord(d->ev_begin, s));
+    /* gaps between frames (K % 8 != 0, decodeCL.c:191-192 leaves them alone) read as 0 */
+    if (out_dev) HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)std::min(out_bytes, need), s));
+    int rc;
+    if (d->cfg.algo == LDPC_ALGO_LAYERED) {
+        ldpc::LayeredRun run{llr_dev, frames, out_dev, std::min(out_bytes, need), iters_dev,
+                             d->cfg.K, d->cfg.max_iter, d->tap_iter, d->cfg.early_term,
+                             d->cfg.pack_mode, d->hard.p, d->failw.p, d->done.p, d->iters.p,
+                             d->row_ptr.p, d->edge_col.p, d->summary.p};
+        hipError_t e = ldpc::layered_run(&d->layered, run, s, &d->last_iterations);
+        rc = (e == hipSuccess) ? LDPC_OK
+                               : fail(LDPC_ERR_HIP, "layered decode: %s", hipGetErrorString(e));
+    } else if (d->V == 1) rc = run_flooding<1>(d, llr_dev, frames, out_dev, std::min(out_bytes, need), iters_dev, s);
+    else if (d->V == 2) rc = run_flooding<2>(d, llr_dev, frames, out_dev, std::min(out_bytes, need), iters_dev, s);
+    else rc = run_flooding<4>(d, llr_dev, frames, out_dev, std::min(out_bytes, need), iters_dev, s);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(d->ev_end, s));
+    d->have_last = true;
+    return LDPC_OK;
+}
+
+int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t *out_host,
+                int64_t out_bytes, int32_t *iters)
+{
+    if (!d) return fail(LDPC_ERR_ARG, "decoder is NULL");
+    if (frames < 0) return fail(LDPC_ERR_ARG, "frames < 0");
+    if (frames == 0) return LDPC_OK;
+    if (!llr_host || !out_host) return fail(LDPC_ERR_ARG, "llr/out is NULL");
+    const int64_t total = ldpc_out_bytes(d->cfg.K, frames, d->cfg.pack_mode);
+    if (out_bytes < 0) return fail(LDPC_ERR_ARG, "out_bytes < 0");
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    const int64_t B = d->cfg.max_batch;
+    if (!d->llr_stage.p) {
+        HIP_TRY(d->llr_stage.alloc((size_t)B * d->N));
+        HIP_TRY(d->out_stage.alloc((size_t)ldpc_out_bytes(d->cfg.K, B, d->cfg.pack_mode) + 8));
+        HIP_TRY(d->iters_stage.alloc((size_t)B));
+    }
+    if (d->cfg.pack_mode == LDPC_PACK_BITS && (d->cfg.K % 8) && frames > B)
+        return fail(LDPC_ERR_UNSUPPORTED, "bit-packed output with K %% 8 != 0 cannot be chunked: "
+                    "raise max_batch to cover all %lld frames", (long long)frames);
+    /* Coder::decode, MyLdpc.cpp:577-616: groups of batchSize frames, last one short */
+    for (int64_t off = 0; off < frames; off += B) {
+        const int64_t n = std::min(B, frames - off);
+        HIP_TRY(hipMemcpyAsync(d->llr_stage.p, llr_host + (size_t)off * d->N,
+                               (size_t)n * d->N * sizeof(float), hipMemcpyHostToDevice, d->stream));
+        const int64_t chunk_bytes = ldpc_out_bytes(d->cfg.K, n, d->cfg.pack_mode);
+        int rc = ldpc_decode_device(d, d->llr_stage.p, n, d->out_stage.p, chunk_bytes,
+                                    iters ? d->iters_stage.p : nullptr, d->stream);
+        if (rc) return rc;
+        /* byte offset of this group's first frame: (off*K)/8 in both packings */
+        const int64_t dst = off * (int64_t)d->cfg.K / 8;
+        const int64_t room = std::min(out_bytes, total) - dst;
+        if (room > 0)
+            HIP_TRY(hipMemcpyAsync(out_host + dst, d->out_stage.p, (size_t)std::min(room, chunk_bytes),
+                                   hipMemcpyDeviceToHost, d->stream));
+        if (iters)
+            HIP_TRY(hipMemcpyAsync(iters + off, d->iters_stage.p, (size_t)n * sizeof(int32_t),
+                                   hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+    }
+    return LDPC_OK;
+}
+
+int ldpc_decoder_set_timing(ldpc_decoder *d, int enable)
+{
+    if (!d) return fail(LDPC_ERR_ARG, "decoder is NULL");
+    d->timing = enable != 0;
+    return LDPC_OK;
+}
+
+int ldpc_decoder_stats(ldpc_decoder *d, ldpc_decode_stats *st)
+{
+    if (!d || !st) return fail(LDPC_ERR_ARG, "decoder/stats is NULL");
+    memset(st, 0, sizeof *st);
+    if (!d->have_last) return fail(LDPC_ERR_STATE, "no decode call to report on");
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    HIP_TRY(hipEventSynchronize(d->ev_end));
+    st->iterations_launched = d->last_iterations;
+    st->frames = d->last_frames;
+    HIP_TRY(hipEventElapsedTime(&st->ms_total, d->ev_begin, d->ev_end));
+    int32_t summary[2] = {0, 0};
+    HIP_TRY(hipMemcpy(summary, d->summary.p, sizeof summary, hipMemcpyDeviceToHost));
+    st->batch_time = summary[0];
+    st->frames_converged = summary[1];
+    for (size_t i = 0; i < d->spans_used; ++i) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, d->spans[i].a, d->spans[i].b));
+        if (d->spans[i].kind == 0) { st->ms_check += ms; ++st->launches_check; }
+        else if (d->spans[i].kind == 1) { st->ms_var += ms; ++st->launches_var; }
+        else st->ms_other += ms;
+    }
+    return LDPC_OK;
+}
+
+int ldpc_decoder_set_tap(ldpc_decoder *d, int32_t iter)
+{
+    if (!d) return fail(LDPC_ERR_ARG, "decoder is NULL");
+    if (iter < 0) return fail(LDPC_ERR_ARG, "iter < 0");
+    d->tap_iter = iter;
+    return LDPC_OK;
+}
+
+int ldpc_decoder_dump(ldpc_decoder *d, int32_t which, float *host_out, int64_t count)
+{
+    if (!d || !host_out) return fail(LDPC_ERR_ARG, "decoder/host_out is NULL");
+    if (!d->have_last) return fail(LDPC_ERR_STATE, "no decode call to dump");
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    const int64_t frames = d->last_frames;
+    const int V = d->V, F = d->F;
+    const int tiles = (int)((frames + F - 1) / F);
+    if (d->cfg.algo == LDPC_ALGO_LAYERED) {
+        hipError_t e = ldpc::layered_dump(&d->layered, which, host_out, count, frames, d->hard.p,
+                                          d->h_cols.data());
+        if (e == hipErrorInvalidValue) return fail(LDPC_ERR_ARG, "bad `which`/count for layered dump");
+        if (e != hipSuccess) return fail(LDPC_ERR_HIP, "layered dump: %s", hipGetErrorString(e));
+        return LDPC_OK;
+    }
+    if (which == 0 || which == 1 || which == 2) {
+        const int64_t per = (which == 2) ? d->N : d->E;
+        if (count != frames * per) return fail(LDPC_ERR_ARG, "count must be frames*%lld", (long long)per);
+        const float *src = which == 0 ? d->R.p : (which == 1 ? d->Q.p : d->chan.p);
+        std::vector<float> tile((size_t)per * F);
+        for (int t = 0; t < tiles; ++t) {
+            HIP_TRY(hipMemcpy(tile.data(), src + (size_t)t * per * F, tile.size() * sizeof(float),
+                              hipMemcpyDeviceToHost));
+            for (int fi = 0; fi < F; ++fi) {
+                const int64_t f = (int64_t)t * F + fi;
+                if (f >= frames) break;
+                for (int64_t i = 0; i < per; ++i) host_out[f * per + i] = tile[(size_t)i * F + fi];
+            }
+        }
+        return LDPC_OK;
+    }
+    if (which == 3) {
+        if (count != frames * d->N) return fail(LDPC_ERR_ARG, "count must be frames*N");
+        std::vector<uint64_t> w((size_t)tiles * d->N * V);
+        HIP_TRY(hipMemcpy(w.data(), d->hard.p, w.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        for (int64_t f = 0; f < frames; ++f) {
+            const int64_t t = f / F;
+            const int fi = (int)(f % F);
+            for (int32_t n = 0; n < d->N; ++n)
+                host_out[f * d->N + n] =
+                    (float)((w[((size_t)t * d->N + n) * V + fi % V] >> (fi / V)) & 1ull);
+        }
+        return LDPC_OK;
+    }
+    return fail(LDPC_ERR_ARG, "unknown `which` %d", which);
+}
+
+}  /* extern "C" */

@@ -1,0 +1,224 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the golden vectors
+made from the reference's kernels and against the CPU oracle, bit for bit."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+import myldpccppapi_amd as L
+from myldpccppapi_amd import channel, codes
+from util import golden_files, load_golden, wimax_oracle_graph
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FLOOD = golden_files("flood")
+LAYERED = golden_files("layered")
+f32 = np.float32
+
+
+def _graph(rate, N):
+    og, rows, cols, K, M, z = wimax_oracle_graph(rate, N)
+    return L.Graph(rows, cols, M, N), og, K, M, z
+
+
+@pytest.mark.parametrize("path", FLOOD, ids=lambda p: p.split("flood_")[-1][:-4])
+@pytest.mark.parametrize("algo", ["ms", "sp"])
+@pytest.mark.parametrize("V", [1, 2, 4])
+def test_flooding_bit_exact_vs_reference_golden(built, path, algo, V):
+    gd = load_golden(path)
+    g, og, K, M, z = _graph(int(gd["rate"]), int(gd["N"]))
+    y = gd["y"]
+    B = y.shape[0]
+    dec = L.Decoder(g, K, max_batch=B, algo=algo, max_iter=int(gd["times"]), frames_per_lane=V)
+    out, iters = dec.decode(y)
+    assert np.array_equal(out, gd[algo + "_out"])                       # the reference's bytes
+    st = dec.stats()
+    assert st["batch_time"] == int(gd[algo + "_time"])                  # its "Time="
+    assert st["frames_converged"] == int((gd[algo + "_flags"] == 0).sum())
+    o = oracle.decode(og, y, algo, max_iter=int(gd["times"]))
+    assert np.array_equal(iters, o["iters"])
+    # all N hard bits, not only the K packed ones
+    assert np.array_equal(dec.dump(3, B).astype(np.uint8), gd[algo + "_hard"])
+    dec.close()
+
+
+@pytest.mark.parametrize("path", FLOOD[:4] + FLOOD[-2:], ids=lambda p: p.split("flood_")[-1][:-4])
+@pytest.mark.parametrize("algo", ["ms", "sp"])
+def test_intermediate_messages_bit_exact(built, path, algo):
+    """Messages after `tap_iter` rounds, compared bitwise (tolerance 0 ulp) with what the
+    reference kernels hold, on frames still running at that round."""
+    gd = load_golden(path)
+    g, og, K, M, z = _graph(int(gd["rate"]), int(gd["N"]))
+    y, tap = gd["y"], int(gd["tap_iter"])
+    B = y.shape[0]
+    o = oracle.decode(og, y, algo, max_iter=int(gd["times"]))
+    dec = L.Decoder(g, K, max_batch=B, algo=algo, max_iter=int(gd["times"]), frames_per_lane=2)
+    dec.set_tap(tap)
+    dec.decode(y)
+    R, Q = dec.dump(0, B), dec.dump(1, B)
+    run_r = np.nonzero(o["iters"] >= tap)[0]
+    run_q = np.nonzero(o["iters"] > tap)[0]
+    assert len(run_r) > 0
+    if algo == "ms":
+        assert np.array_equal(R[run_r], gd["ms_tap_r"][run_r], equal_nan=True)
+        assert np.array_equal(Q[run_q], gd["ms_tap_q"][run_q], equal_nan=True)
+    else:
+        # stored d = r0 - r1 form: r0 = (1+d)/2, r1 = (1-d)/2 (decodeCL.c:39-40), d_q = q0 - q1 (:37)
+        r0 = (f32(1) + R) * f32(0.5)
+        r1 = (f32(1) - R) * f32(0.5)
+        assert np.array_equal(r0[run_r], gd["sp_tap_r0"][run_r], equal_nan=True)
+        assert np.array_equal(r1[run_r], gd["sp_tap_r1"][run_r], equal_nan=True)
+        dq = gd["sp_tap_q0"] - gd["sp_tap_q1"]
+        assert np.array_equal(Q[run_q], dq[run_q], equal_nan=True)
+        t = dec.dump(2, B)                                            # exp(8 y), decodeCL.c:9
+        want = np.array([np.exp(np.float64(8.0 * v)) for v in y.ravel()], np.float64)
+        assert np.allclose(t.ravel(), want, rtol=1e-6)
+    dec.close()
+
+
+@pytest.mark.parametrize("path", LAYERED, ids=lambda p: p.split("layered_")[-1][:-4])
+@pytest.mark.parametrize("V", [1, 2, 4])
+def test_layered_bit_exact_vs_fused_reference_kernel(built, path, V):
+    gd = load_golden(path)
+    g, og, K, M, z = _graph(int(gd["rate"]), int(gd["N"]))
+    y = gd["y"]
+    dec = L.Decoder(g, K, max_batch=y.shape[0], algo="layered", max_iter=int(gd["times"]),
+                    layer_rows=z, frames_per_lane=V)
+    out, iters = dec.decode(y)
+    assert np.array_equal(out, gd["out"])
+    o = oracle.decode(og, y, "layered", max_iter=int(gd["times"]), layer_rows=z, tap_iter=2)
+    assert np.array_equal(iters, o["iters"])
+    dec.set_tap(2)
+    dec.decode(y)
+    run = np.nonzero(o["iters"] >= 2)[0]
+    assert np.array_equal(dec.dump(0, y.shape[0])[run], o["taps"]["r"][run])
+    assert np.array_equal(dec.dump(2, y.shape[0])[run], o["taps"]["post"][run])
+    dec.close()
+
+
+@pytest.mark.parametrize("algo", ["ms", "sp", "layered"])
+def test_ragged_batches_and_chunking(built, algo):
+    """frames not a multiple of the tile, more frames than max_batch (Coder::decode's
+    chunk loop, MyLdpc.cpp:577-616), a single frame, zero frames."""
+    rate, N = codes.RATE_2_3_B, 960
+    g, og, K, M, z = _graph(rate, N)
+    y = channel.awgn_frames(N, 0, 150, 0.66, seed=3)
+    want = oracle.decode(og, y, algo, layer_rows=z)
+    for max_batch, V in ((150, 1), (64, 1), (70, 2), (33, 4), (256, 4)):
+        dec = L.Decoder(g, K, max_batch=max_batch, algo=algo, layer_rows=z, frames_per_lane=V)
+        out, iters = dec.decode(y)
+        assert np.array_equal(out, want["out"]), (max_batch, V)
+        assert np.array_equal(iters, want["iters"])
+        out1, it1 = dec.decode(y[5:6])
+        assert np.array_equal(out1, oracle.decode(og, y[5:6], algo, layer_rows=z)["out"])
+        out0, _ = dec.decode(np.zeros((0, N), np.float32))
+        assert out0.size == 0
+        dec.close()
+
+
+@pytest.mark.parametrize("algo", ["ms", "sp", "layered"])
+def test_k_not_byte_aligned_and_bit_packing(built, algo):
+    """(648, 324): K/8 = 40.5.  toChar packs 40 whole bytes at (b*K)/8 (decodeCL.c:191-192);
+    decodeCPU packs bit b*K+i (MyLdpc.cpp:765-774)."""
+    g, og, K, M, z = _graph(codes.RATE_1_2, 648)
+    y = channel.awgn_frames(648, 0, 11, 0.8, seed=4)
+    for mode in (L.PACK_BYTES, L.PACK_BITS):
+        dec = L.Decoder(g, K, max_batch=16, algo=algo, layer_rows=z, pack_mode=mode)
+        out, iters = dec.decode(y)
+        want = oracle.decode(og, y, algo, layer_rows=z, pack_mode=mode)
+        assert np.array_equal(out, want["out"]), mode
+        dec.close()
+
+
+def test_parameters_follow_the_oracle(built):
+    g, og, K, M, z = _graph(codes.RATE_1_2, 1152)
+    y = channel.awgn_frames(1152, 0, 40, 0.85, seed=6)
+    for algo, kw in (("sp", dict(max_iter=20, llr_scale=4.0)), ("sp", dict(max_iter=7, llr_scale=8.0)),
+                     ("ms", dict(max_iter=3)), ("layered", dict(max_iter=5)), ("ms", dict(max_iter=1))):
+        dec = L.Decoder(g, K, max_batch=40, algo=algo, layer_rows=z, **kw)
+        out, iters = dec.decode(y)
+        want = oracle.decode(og, y, algo, layer_rows=z, **kw)
+        assert np.array_equal(out, want["out"]) and np.array_equal(iters, want["iters"]), (algo, kw)
+        dec.close()
+
+
+def test_early_termination_switch_and_polling(built):
+    g, og, K, M, z = _graph(codes.RATE_3_4_B, 576)
+    y = channel.awgn_frames(576, 0, 100, 0.45, seed=8)            # everything converges quickly
+    want = oracle.decode(og, y, "sp")
+    dec = L.Decoder(g, K, max_batch=128, algo="sp", poll_interval=1)
+    out, iters = dec.decode(y)
+    assert np.array_equal(out, want["out"]) and np.array_equal(iters, want["iters"])
+    st = dec.stats()
+    assert st["iterations_launched"] == int(want["iters"].max()) < 40   # host stopped early
+    assert st["frames_converged"] == 100
+    dec.close()
+    # early_term off: all rounds run, frames are not frozen; noisy frames (never clean) are
+    # unaffected by the switch
+    yn = channel.awgn_frames(576, 0, 20, 1.3, seed=9)
+    wn = oracle.decode(og, yn, "ms")
+    assert wn["iters"].min() == 40
+    dec = L.Decoder(g, K, max_batch=32, algo="ms", early_term=False)
+    out, iters = dec.decode(yn)
+    assert np.array_equal(out, wn["out"])
+    assert dec.stats()["iterations_launched"] == 40
+    dec.close()
+
+
+def test_generic_degree_kernels(built):
+    """Degrees above the unrolled range take the generic kernels: the rate-5/6 seed has
+    row weight 20 (flooding check / layered rows)."""
+    g, og, K, M, z = _graph(codes.RATE_5_6, 1152)
+    assert g.info()["max_row_deg"] == 20
+    y = channel.awgn_frames(1152, 0, 30, 0.42, seed=10)
+    for algo in ("ms", "sp"):
+        dec = L.Decoder(g, K, max_batch=32, algo=algo)
+        out, iters = dec.decode(y)
+        want = oracle.decode(og, y, algo)
+        assert np.array_equal(out, want["out"]) and np.array_equal(iters, want["iters"])
+        dec.close()
+
+
+def test_device_buffers_and_misuse(built):
+    import torch
+    g, og, K, M, z = _graph(codes.RATE_1_2, 576)
+    y = channel.awgn_frames(576, 0, 48, 0.8, seed=11)
+    dec = L.Decoder(g, K, max_batch=48, algo="ms")
+    yd = torch.from_numpy(y).cuda()
+    out = torch.empty(L.out_bytes(K, 48), dtype=torch.uint8, device="cuda")
+    it = torch.empty(48, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        dec.decode_device(yd.data_ptr(), 48, out.data_ptr(), out.numel(), it.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    want = oracle.decode(og, y, "ms")
+    assert np.array_equal(out.cpu().numpy(), want["out"]) and np.array_equal(it.cpu().numpy(), want["iters"])
+    with pytest.raises(L.LdpcError) as e:
+        dec.decode_device(yd.data_ptr(), 49, out.data_ptr(), out.numel())     # more than max_batch
+    assert e.value.code == 1
+    with pytest.raises(L.LdpcError):
+        dec.decode_device(None, 4, out.data_ptr(), out.numel())
+    dec.close()
+    with pytest.raises(L.LdpcError):
+        L.Decoder(g, K, 8, algo="layered", layer_rows=7)                       # does not divide M
+    with pytest.raises(L.LdpcError):
+        L.Decoder(g, K, 8, algo="ms", device=99)
+
+
+def test_cpp_coder_round_trip_like_test_cpp(built, tmp_path):
+    """The reference's own pass signal (Test.cpp:105-110): ErrNum=0 after encode -> AWGN ->
+    decode, for every decode mode of the C++ Coder class."""
+    exe = str(tmp_path / "coder_roundtrip")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "coder_roundtrip.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "myldpccppapi_amd"), "-lmyldpc", "-lldpc_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "myldpccppapi_amd")])
+    for mode in ("SP", "MS", "CPU", "TDMP", "TDMPCL"):
+        # Test.cpp's code: z = 24, rate 3/4B; 10 kB payload, batch 64, 6 dB
+        out = subprocess.run([exe, "4", "576", "10000", "64", "6", mode], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "ParityFail=0" in out.stdout and "ErrNum=0" in out.stdout, out.stdout
+    out = subprocess.run([exe, "0", "2304", "5000", "16", "3.5", "SP"], capture_output=True, text=True)
+    assert "ErrNum=0" in out.stdout, out.stdout

@@ -1,0 +1,191 @@
+"""Host logic and the C ABI surface without a GPU: the library loads, exports every
+symbol include/ldpc_hip.h declares, validates its arguments, and -- on a box
+without a HIP device -- refuses to decode instead of falling back to a CPU path."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+import myldpccppapi_amd as L
+from myldpccppapi_amd import _lib, channel, codes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "ldpc_hip.h")).read()
+    declared = set(re.findall(r"\b(ldpc_[a-z_]+)\s*\(", header))
+    declared -= {"ldpc_graph", "ldpc_decoder"}
+    assert declared == set(_lib.EXPORTS)
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert lib.ldpc_abi_version() == 1
+
+
+def test_out_bytes_follows_tochar_and_decodecpu(built):
+    assert L.out_bytes(432, 8) == 8 * 54
+    # K % 8 != 0: frame b starts at (b*K)/8, each frame writes K/8 whole bytes (decodeCL.c:191-192)
+    assert L.out_bytes(324, 9) == (8 * 324) // 8 + 40
+    assert L.out_bytes(324, 9, L.PACK_BITS) == (9 * 324 + 7) // 8
+    assert L.out_bytes(324, 0) == 0
+
+
+def test_graph_validation(built):
+    rows, cols = codes.wimax_edges(codes.RATE_1_2, 648)
+    g = L.Graph(rows, cols, 324, 648)
+    info = g.info()
+    assert info == dict(M=324, N=648, E=2052, max_row_deg=7, max_col_deg=6)
+    with pytest.raises(L.LdpcError) as e:
+        L.Graph(rows[::-1].copy(), cols[::-1].copy(), 324, 648)      # not row-major
+    assert e.value.code == 1 and "row-major" in str(e.value)
+    with pytest.raises(L.LdpcError):
+        L.Graph(rows, cols, 100, 648)                                  # row out of range
+    with pytest.raises(L.LdpcError):
+        L.Graph(np.r_[rows, rows[-1]], np.r_[cols, cols[-1]], 324, 648)  # duplicate edge
+
+
+def test_config_defaults_are_the_references(built):
+    cfg = _lib.DecoderConfig()
+    _lib.load().ldpc_decoder_config_init(ctypes.byref(cfg))
+    assert cfg.struct_size == ctypes.sizeof(_lib.DecoderConfig)
+    assert cfg.max_iter == 40            # MyLdpc.cpp:24
+    assert cfg.llr_scale == 8.0          # decodeCL.c:9
+    assert cfg.early_term == 1 and cfg.algo == L.ALGO_SP and cfg.pack_mode == L.PACK_BYTES
+
+
+def test_no_cpu_fallback_without_a_device(built):
+    if L.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    rows, cols = codes.wimax_edges(codes.RATE_1_2, 648)
+    g = L.Graph(rows, cols, 324, 648)
+    with pytest.raises(L.LdpcError) as e:
+        L.Decoder(g, 324, 8, algo="ms")
+    assert e.value.code == 2             # LDPC_ERR_HIP: no silent CPU path
+
+
+def test_bad_config_is_rejected_before_touching_the_device(built):
+    rows, cols = codes.wimax_edges(codes.RATE_1_2, 648)
+    g = L.Graph(rows, cols, 324, 648)
+    for kw in (dict(K=0), dict(max_batch=0), dict(max_iter=0), dict(algo=7), dict(frames_per_lane=3),
+               dict(pack_mode=5)):
+        args = dict(K=324, max_batch=4, algo="ms", max_iter=40)
+        args.update(kw)
+        with pytest.raises(L.LdpcError) as e:
+            L.Decoder(g, args.pop("K"), args.pop("max_batch"), **args)
+        assert e.value.code == 1, kw
+
+
+# ---------------------------------------------------------------- host-side data
+
+@pytest.mark.parametrize("rate", range(6))
+def test_wimax_edges_three_ways(rate):
+    """numpy builder == oracle C builder (== the C++ Coder, checked in test_cpp_coder)."""
+    for N in (576, 960, 2304):
+        r, c = codes.wimax_edges(rate, N)
+        ro, co = oracle.wimax_edges(rate, N)
+        assert np.array_equal(r, ro) and np.array_equal(c, co)
+        K, M, z = codes.wimax_dims(rate, N)
+        assert r.max() == M - 1 and c.max() == N - 1
+
+
+def test_dvbs2_profile_structure():
+    r, c = codes.dvbs2_profile_edges(64800, 32400)
+    assert len(r) == 226799                       # E of the rate-1/2 code
+    rd, cd = np.bincount(r), np.bincount(c)
+    assert rd[0] == 6 and np.all(rd[1:] == 7)     # check degree 7, first row 6
+    assert np.all(cd[:12960] == 8) and np.all(cd[12960:32400] == 3)
+    assert np.all(cd[32400:-1] == 2) and cd[-1] == 1
+    r2, c2 = codes.dvbs2_profile_edges(64800, 32400)
+    assert np.array_equal(r, r2) and np.array_equal(c, c2)   # seeded: reproducible
+    r9, c9 = codes.dvbs2_profile_edges(64800, 58320)
+    assert len(r9) == 194399 and np.bincount(r9)[1:].max() == 30
+
+
+def test_bg1_profile_layers_are_column_disjoint():
+    Z = 48
+    r, c = codes.nr_bg1_profile_edges(Z)
+    assert len(r) == 316 * Z
+    for layer in range(46):
+        cs = c[(r >= layer * Z) & (r < (layer + 1) * Z)]
+        assert len(np.unique(cs)) == len(cs)
+
+
+def test_channel_is_counter_based():
+    a = channel.awgn_frames(648, 0, 6, 0.8, seed=5)
+    b = channel.awgn_frames(648, 4, 2, 0.8, seed=5)
+    assert np.array_equal(a[4:], b)
+    assert abs(channel.snr_db_to_sd(3.0) - 0.7079458) < 1e-6        # Test.cpp:56
+
+
+def test_shared_expf_matches_libm_on_a_sample(tmp_path):
+    """ldpc_expf (used by the SP init kernel) against the host libm the oracle uses.
+    tools/check_expf.c does all 2^32 inputs; here 4M samples + edge cases."""
+    src = tmp_path / "e.c"
+    src.write_text('#include "%s/myldpccppapi_amd/csrc/ldpc_expf.h"\n'
+                   'void run(const float*x,float*y,long n){for(long i=0;i<n;++i)y[i]=ldpc_expf(x[i]);}\n' % ROOT)
+    so = tmp_path / "e.so"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", str(src), "-o", str(so), "-lm"])
+    lib = ctypes.CDLL(str(so))
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-110, 95, 2_000_000), 8 * (1 + rng.standard_normal(2_000_000)),
+                        [0.0, -0.0, 88.72, 88.73, -103.9, -104.0, np.inf, -np.inf, 1e-30,
+                         float.fromhex("0x1.04845ep+5"), float.fromhex("-0x1.f8cbb2p+5")]]).astype(np.float32)
+    y = np.empty_like(x)
+    lib.run(x.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(x.size))
+    libm = ctypes.CDLL("libm.so.6")
+    libm.expf.restype = ctypes.c_float
+    libm.expf.argtypes = [ctypes.c_float]
+    idx = np.r_[rng.integers(0, x.size, 200_000), np.arange(x.size - 11, x.size)]
+    want = np.array([libm.expf(float(v)) for v in x[idx]], np.float32)
+    assert np.array_equal(y[idx].view(np.uint32), want.view(np.uint32))
+
+
+# ------------------------------------------------------------- oracle vs reference
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/decodeCL.c"),
+                    reason="the reference exists only in the build container")
+def test_oracle_against_reference_kernels_on_fresh_seeds():
+    from oracle import refkernels as rk
+    rng = np.random.default_rng(20261004)
+    for rate, N, sigma, B in [(0, 648, 0.8, 6), (3, 576, 0.55, 6), (1, 672, 0.7, 4), (0, 1152, 0.95, 3)]:
+        K, M, z = codes.wimax_dims(rate, N)
+        rows, cols = codes.wimax_edges(rate, N)
+        g = oracle.Graph(rows, cols, M, N, K)
+        rg = rk.RefGraph(rows, cols, M, N, K)
+        y = (1.0 + sigma * rng.standard_normal((B, N))).astype(np.float32)
+        for algo in ("ms", "sp"):
+            o = oracle.decode(g, y, algo)
+            r = rk.decode(rg, y, algo)
+            assert np.array_equal(o["out"], r["out"]) and np.array_equal(o["hard"], r["hard"])
+            assert int(o["iters"].max()) == r["time"]
+        if rate != 1:
+            from myldpccppapi_amd.wimax_seeds import SEEDS
+            o = oracle.decode(g, y, "layered", layer_rows=z)
+            assert np.array_equal(o["out"], rk.decode_tdmp_fused(z, np.array(SEEDS[rate], np.int8), y))
+
+
+# ------------------------------------------------------------------- C++ Coder
+
+def _build_roundtrip(tmp_path):
+    exe = str(tmp_path / "coder_roundtrip")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "coder_roundtrip.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "myldpccppapi_amd"), "-lmyldpc", "-lldpc_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "myldpccppapi_amd")])
+    return exe
+
+
+def test_cpp_coder_encoder_satisfies_h(built, tmp_path):
+    """Coder::encode (structured solve) produces systematic codewords with H c = 0 for
+    all six rates, short last frames included.  CPU only."""
+    exe = _build_roundtrip(tmp_path)
+    for rate in range(6):
+        for N, src in ((576, 1000), (2304, 777)):
+            out = subprocess.run([exe, str(rate), str(N), str(src), "4", "3", "ENC"],
+                                 capture_output=True, text=True)
+            assert out.returncode == 0 and "ParityFail=0" in out.stdout, (rate, N, out.stdout)
