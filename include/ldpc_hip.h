@@ -137,10 +137,26 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
 
 int64_t ldpc_out_bytes(int32_t K, int64_t frames, int32_t pack_mode);
 
-/* Per-kernel HIP-event timing of subsequent decode calls (adds event records;
- * off by default).  Stats of the last call; blocks until that call has finished. */
+/* Per-kernel HIP-event timing of subsequent decode calls (two event records per
+ * launch on the decode stream; off by default).  Enabling (again) clears what was
+ * gathered; times then accumulate over all following calls.
+ * ldpc_decoder_stats: stats of the last call (ms_check/ms_var/ms_other: everything
+ * gathered since timing was enabled); blocks until that call has finished. */
 int ldpc_decoder_set_timing(ldpc_decoder *d, int enable);
 int ldpc_decoder_stats(ldpc_decoder *d, ldpc_decode_stats *stats);
+
+/* One line per distinct kernel launched since timing was enabled. */
+typedef struct ldpc_kernel_time {
+    int32_t phase;         /* 0 check node, 1 variable node, 2 layer, 3 other          */
+    int32_t degree;        /* row / column degree the kernel is specialised for        */
+    int32_t launches;
+    float ms_total;        /* sum of HIP-event durations of those launches             */
+    int64_t bytes_total;   /* ALGORITHMIC bytes of those launches: 4 B per message read
+                              or written + 4 B per channel value read, per frame        */
+    char name[64];         /* e.g. "check_kernel<sp,7,4>" (algo, degree, frames/lane)  */
+} ldpc_kernel_time;
+int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t capacity,
+                              int32_t *count);
 
 /* ---- debug taps (tolerance checks against the oracle) ------------------------
  * Stop the NEXT decode call after `iter` check/variable rounds (0 = off) and keep

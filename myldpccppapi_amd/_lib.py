@@ -39,12 +39,19 @@ class DecodeStats(ctypes.Structure):
                 ("launches_check", ctypes.c_int32), ("launches_var", ctypes.c_int32)]
 
 
+class KernelTime(ctypes.Structure):
+    """Mirror of `ldpc_kernel_time`."""
+    _fields_ = [("phase", ctypes.c_int32), ("degree", ctypes.c_int32), ("launches", ctypes.c_int32),
+                ("ms_total", ctypes.c_float), ("bytes_total", ctypes.c_int64), ("name", ctypes.c_char * 64)]
+
+
 #: every symbol include/ldpc_hip.h declares
 EXPORTS = (
     "ldpc_abi_version", "ldpc_last_error", "ldpc_device_count", "ldpc_graph_create",
     "ldpc_graph_destroy", "ldpc_graph_info", "ldpc_decoder_config_init", "ldpc_decoder_create",
     "ldpc_decoder_destroy", "ldpc_decode", "ldpc_decode_device", "ldpc_out_bytes",
-    "ldpc_decoder_set_timing", "ldpc_decoder_stats", "ldpc_decoder_set_tap", "ldpc_decoder_dump",
+    "ldpc_decoder_set_timing", "ldpc_decoder_stats", "ldpc_decoder_kernel_times", "ldpc_decoder_set_tap",
+    "ldpc_decoder_dump",
 )
 
 
@@ -85,6 +92,7 @@ def load():
     L.ldpc_out_bytes.restype = ctypes.c_int64
     L.ldpc_decoder_set_timing.argtypes = [vp, ctypes.c_int]
     L.ldpc_decoder_stats.argtypes = [vp, ctypes.POINTER(DecodeStats)]
+    L.ldpc_decoder_kernel_times.argtypes = [vp, ctypes.POINTER(KernelTime), ctypes.c_int32, i32p]
     L.ldpc_decoder_set_tap.argtypes = [vp, ctypes.c_int32]
     L.ldpc_decoder_dump.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int64]
     _lib = L

@@ -110,6 +110,15 @@ class Decoder:
         _lib.check(_lib.load().ldpc_decoder_stats(self._h, ctypes.byref(st)))
         return {f: getattr(st, f) for f, _ in st._fields_}
 
+    def kernel_times(self):
+        """Per-kernel HIP-event times gathered since set_timing(True)."""
+        arr = (_lib.KernelTime * 64)()
+        n = ctypes.c_int32(0)
+        _lib.check(_lib.load().ldpc_decoder_kernel_times(self._h, arr, 64, ctypes.byref(n)))
+        return [dict(name=arr[i].name.decode(), phase=arr[i].phase, degree=arr[i].degree,
+                     launches=arr[i].launches, ms_total=arr[i].ms_total, bytes_total=arr[i].bytes_total)
+                for i in range(n.value)]
+
     def set_tap(self, it):
         _lib.check(_lib.load().ldpc_decoder_set_tap(self._h, int(it)))
 

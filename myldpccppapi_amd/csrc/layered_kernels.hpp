@@ -291,6 +291,10 @@ inline int layered_plan_create(LayeredPlan *pl, int32_t M, int32_t N, int64_t E,
 }
 
 struct LayeredRun {
+    /* optional per-launch timing hooks (HIP events on the decode stream) */
+    hipError_t (*span_begin)(void *ctx, hipStream_t s, int kind, int degree, int64_t bytes) = nullptr;
+    hipError_t (*span_end)(void *ctx, hipStream_t s) = nullptr;
+    void *span_ctx = nullptr;
     const float *llr_dev;
     int64_t frames;
     uint8_t *out_dev;
@@ -353,7 +357,10 @@ inline hipError_t layered_run_v(LayeredPlan *pl, const LayeredRun &r, hipStream_
             const int waves = (g.count + a.rows_per_wave - 1) / a.rows_per_wave;
             dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
             const int k = g.degree <= kMaxUnrolledLayerDegree ? g.degree : 0;
+            if (r.span_begin && (e = r.span_begin(r.span_ctx, s, 2, g.degree,
+                                                  (int64_t)16 * g.degree * g.count * r.frames))) return e;
             table[k]<<<grid, kBlock, 0, s>>>(a);
+            if (r.span_end && (e = r.span_end(r.span_ctx, s))) return e;
         }
         /* syndrome of this round's bits, freeze (decodeCL.c:393-410) */
         uint64_t *fw = r.failw + (size_t)it * slot;

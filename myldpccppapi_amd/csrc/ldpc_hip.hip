@@ -129,7 +129,9 @@ struct ColClass {
 
 struct TimedSpan {
     hipEvent_t a, b;
-    int kind; /* 0 check, 1 var, 2 other */
+    int kind;       /* 0 check, 1 var, 2 layer, 3 other */
+    int degree;
+    int64_t bytes;  /* algorithmic bytes of the launch */
 };
 
 }  // namespace
@@ -210,7 +212,7 @@ int pick_frames_per_lane(const ldpc_decoder_config &cfg, int32_t max_deg)
     return 1;
 }
 
-hipError_t span_begin(ldpc_decoder *d, hipStream_t s, int kind)
+hipError_t span_begin(ldpc_decoder *d, hipStream_t s, int kind, int degree = 0, int64_t bytes = 0)
 {
     if (!d->timing) return hipSuccess;
     if (d->spans_used == d->spans.size()) {
@@ -222,6 +224,8 @@ hipError_t span_begin(ldpc_decoder *d, hipStream_t s, int kind)
         d->spans.push_back(t);
     }
     d->spans[d->spans_used].kind = kind;
+    d->spans[d->spans_used].degree = degree;
+    d->spans[d->spans_used].bytes = bytes;
     return hipEventRecord(d->spans[d->spans_used].a, s);
 }
 
@@ -247,7 +251,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
     HIP_TRY(hipMemsetAsync(d->failw.p, 0, d->failw.n * sizeof(uint64_t), s));
     HIP_TRY(hipMemsetAsync(d->summary.p, 0, 2 * sizeof(int32_t), s));
 
-    HIP_TRY(span_begin(d, s, 2));
+    HIP_TRY(span_begin(d, s, 3));
     {
         InitArgs a{llr_dev, d->chan.p, d->Q.p, d->hard.p, d->col_ptr.p, d->col_edge.p,
                    d->E, frames, d->N, d->cfg.llr_scale};
@@ -262,8 +266,8 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
     int launched = 0;
     for (int it = 1; it <= rounds; ++it) {
         /* check_i: R_i = check(Q_{i-1}) */
-        HIP_TRY(span_begin(d, s, 0));
         for (auto &rc : d->row_classes) {
+            HIP_TRY(span_begin(d, s, 0, rc.degree, (int64_t)8 * rc.degree * rc.count * frames));
             CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree};
             const int rpw = d->tune_rpw ? d->tune_rpw : 2;
             a.rows_per_wave = rpw;
@@ -271,11 +275,12 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
             const int slotk = rc.degree <= kMaxUnrolledDegree ? rc.degree : 0;
             d->check_fn[slotk]<<<grid, kBlock, 0, s>>>(a);
+            HIP_TRY(span_end(d, s));
         }
-        HIP_TRY(span_end(d, s));
         /* var_i: bits_i = hard(R_i); Q_i = var(R_i) unless this is the last round */
-        HIP_TRY(span_begin(d, s, 1));
         for (auto &cc : d->col_classes) {
+            HIP_TRY(span_begin(d, s, 1, cc.degree,
+                               (int64_t)((it < max_iter ? 8 : 4) * cc.degree + 4) * cc.count * frames));
             VarArgs a{d->R.p, d->Q.p, d->chan.p, d->hard.p, d->done.p, cc.col.p, cc.edge.p,
                       d->E, d->N, cc.count, 1, (it < max_iter) ? 1 : 0, cc.degree};
             const int cpw = d->tune_cpw ? d->tune_cpw : 2;
@@ -284,12 +289,12 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
             const int slotk = cc.degree <= kMaxUnrolledDegree ? cc.degree : 0;
             d->var_fn[slotk]<<<grid, kBlock, 0, s>>>(a);
+            HIP_TRY(span_end(d, s));
         }
-        HIP_TRY(span_end(d, s));
         launched = it;
         /* syndrome of bits_i, then freeze the frames that are clean (iters = i) */
         if (freeze || it == rounds) {
-            HIP_TRY(span_begin(d, s, 2));
+            HIP_TRY(span_begin(d, s, 3));
             uint64_t *fw = d->failw.p + (size_t)it * slot;
             SyndromeArgs sa{d->row_ptr.p, d->edge_col.p, d->hard.p, fw, d->done.p, d->M, d->N};
             dim3 sgrid((d->M + kBlock - 1) / kBlock, tiles);
@@ -313,7 +318,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
     }
     d->last_iterations = launched;
 
-    HIP_TRY(span_begin(d, s, 2));
+    HIP_TRY(span_begin(d, s, 3));
     {
         PackArgs pa{d->hard.p, out_dev, d->iters.p, iters_dev, frames, out_bytes, d->N, d->cfg.K,
                     d->cfg.pack_mode};
@@ -584,7 +589,6 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
         return fail(LDPC_ERR_ARG, "out_bytes=%lld < %lld", (long long)out_bytes, (long long)need);
     HIP_TRY(hipSetDevice(d->cfg.device));
     hipStream_t s = (hipStream_t)stream;
-    d->spans_used = 0;
     d->last_stream = s;
     d->last_frames = frames;
     HIP_TRY(hipEventRecord(d->ev_begin, s));
@@ -592,10 +596,18 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
     if (out_dev) HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)std::min(out_bytes, need), s));
     int rc;
     if (d->cfg.algo == LDPC_ALGO_LAYERED) {
-        ldpc::LayeredRun run{llr_dev, frames, out_dev, std::min(out_bytes, need), iters_dev,
-                             d->cfg.K, d->cfg.max_iter, d->tap_iter, d->cfg.early_term,
-                             d->cfg.pack_mode, d->hard.p, d->failw.p, d->done.p, d->iters.p,
-                             d->row_ptr.p, d->edge_col.p, d->summary.p};
+        ldpc::LayeredRun run;
+        run.span_begin = [](void *c, hipStream_t st, int kind, int deg, int64_t bytes) {
+            return span_begin((ldpc_decoder *)c, st, kind, deg, bytes);
+        };
+        run.span_end = [](void *c, hipStream_t st) { return span_end((ldpc_decoder *)c, st); };
+        run.span_ctx = d;
+        run.llr_dev = llr_dev; run.frames = frames; run.out_dev = out_dev;
+        run.out_bytes = std::min(out_bytes, need); run.iters_dev = iters_dev;
+        run.K = d->cfg.K; run.max_iter = d->cfg.max_iter; run.tap_iter = d->tap_iter;
+        run.early_term = d->cfg.early_term; run.pack_mode = d->cfg.pack_mode;
+        run.hard = d->hard.p; run.failw = d->failw.p; run.done = d->done.p; run.iters = d->iters.p;
+        run.row_ptr = d->row_ptr.p; run.edge_col = d->edge_col.p; run.summary = d->summary.p;
         hipError_t e = ldpc::layered_run(&d->layered, run, s, &d->last_iterations);
         rc = (e == hipSuccess) ? LDPC_OK
                                : fail(LDPC_ERR_HIP, "layered decode: %s", hipGetErrorString(e));
@@ -653,7 +665,12 @@ int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
 int ldpc_decoder_set_timing(ldpc_decoder *d, int enable)
 {
     if (!d) return fail(LDPC_ERR_ARG, "decoder is NULL");
+    if (d->have_last) {   /* events of earlier calls may still be pending */
+        HIP_TRY(hipSetDevice(d->cfg.device));
+        HIP_TRY(hipEventSynchronize(d->ev_end));
+    }
     d->timing = enable != 0;
+    d->spans_used = 0;
     return LDPC_OK;
 }
 
@@ -675,8 +692,41 @@ int ldpc_decoder_stats(ldpc_decoder *d, ldpc_decode_stats *st)
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, d->spans[i].a, d->spans[i].b));
         if (d->spans[i].kind == 0) { st->ms_check += ms; ++st->launches_check; }
-        else if (d->spans[i].kind == 1) { st->ms_var += ms; ++st->launches_var; }
+        else if (d->spans[i].kind == 1 || d->spans[i].kind == 2) { st->ms_var += ms; ++st->launches_var; }
         else st->ms_other += ms;
+    }
+    return LDPC_OK;
+}
+
+int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t capacity, int32_t *count)
+{
+    if (!d || !out || !count || capacity <= 0) return fail(LDPC_ERR_ARG, "bad arguments");
+    *count = 0;
+    if (!d->have_last) return fail(LDPC_ERR_STATE, "no decode call to report on");
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    HIP_TRY(hipEventSynchronize(d->ev_end));
+    static const char *phase_name[] = {"check_kernel", "var_kernel", "layer_kernel", "other"};
+    static const char *algo_name[] = {"sp", "ms", "layered"};
+    for (size_t i = 0; i < d->spans_used; ++i) {
+        const TimedSpan &sp = d->spans[i];
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, sp.a, sp.b));
+        int k = 0;
+        for (; k < *count; ++k)
+            if (out[k].phase == sp.kind && out[k].degree == sp.degree) break;
+        if (k == *count) {
+            if (*count == capacity) continue;
+            ++*count;
+            memset(&out[k], 0, sizeof out[k]);
+            out[k].phase = sp.kind;
+            out[k].degree = sp.degree;
+            if (sp.kind == 3) snprintf(out[k].name, sizeof out[k].name, "other");
+            else snprintf(out[k].name, sizeof out[k].name, "%s<%s,%d,%d>", phase_name[sp.kind],
+                          algo_name[d->cfg.algo], sp.degree, d->V);
+        }
+        ++out[k].launches;
+        out[k].ms_total += ms;
+        out[k].bytes_total += sp.bytes;
     }
     return LDPC_OK;
 }

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 outputs of tools/profile_bench.sh (gpurun_out/prof_<tag>/) into
+small committed files under profiles/:
+  <tag>_kernel_stats.csv   per-kernel calls / total / average / min / max (from --kernel-trace --stats)
+  <tag>_pmc_traffic.json   per-kernel FETCH_SIZE / WRITE_SIZE averages per launch (separate --pmc passes)
+                           and the HBM bytes they imply, corrected as MI355X_MICROARCH.md (HBM section)
+                           prescribes: counters are in KiB; FETCH_SIZE reports exactly 1/2 of the bytes
+                           of a wide (16 B/lane) coalesced streaming read on gfx950 -> doubled for the
+                           V=4 (16 B per lane) message kernels; WRITE_SIZE is exact for 16 B/lane stores.
+  traffic.json             {kernel display name: corrected HBM bytes per launch} read by bench.py
+usage: tools/summarize_profile.py <tag>"""
+import csv, glob, json, os, re, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+src = os.path.join(root, "gpurun_out", "prof_" + tag)
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(.*$", "", name)
+    name = name.replace("ldpc::", "").replace("(anonymous namespace)::", "")
+    if len(name) > 80:
+        name = name[:77] + "..."
+    return name
+
+
+def display(name):
+    """check_kernel<0, 7, 4> -> check_kernel<sp,7,4> (the names bench.py prints)"""
+    m = re.match(r"(check_kernel|var_kernel)<(\d), (\d+), (\d)>", name)
+    if m:
+        return "%s<%s,%s,%s>" % (m.group(1), ("sp", "ms")[int(m.group(2))], m.group(3), m.group(4))
+    m = re.match(r"layer_kernel<(\d+), (\d)>", name)
+    if m:
+        return "layer_kernel<layered,%s,%s>" % (m.group(1), m.group(2))
+    return name
+
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+rows = []
+if stats:
+    for r in csv.DictReader(open(stats[0])):
+        rows.append([short(r["Name"]), r["Calls"], r["TotalDurationNs"], "%.1f" % float(r["AverageNs"]),
+                     r["Percentage"], r["MinNs"], r["MaxNs"]])
+    with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 (MI355X, 1 GPU)"])
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        w.writerows(rows)
+
+pmc = {}
+for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+    files = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+    if not files:
+        continue
+    acc = {}
+    for r in csv.DictReader(open(files[0])):
+        if r["Counter_Name"] != counter:
+            continue
+        k = short(r["Kernel_Name"])
+        a = acc.setdefault(k, [0, 0.0])
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    for k, (n, tot) in acc.items():
+        pmc.setdefault(k, {})[counter + "_KiB_per_launch"] = tot / n
+        pmc[k]["launches_" + counter] = n
+traffic = {}
+for k, v in pmc.items():
+    if "FETCH_SIZE_KiB_per_launch" in v and "WRITE_SIZE_KiB_per_launch" in v:
+        wide = bool(re.search(r"(check_kernel|var_kernel|layer_kernel)<.*4>$", k))
+        fetch = v["FETCH_SIZE_KiB_per_launch"] * 1024 * (2 if wide else 1)
+        write = v["WRITE_SIZE_KiB_per_launch"] * 1024
+        v["fetch_correction"] = 2 if wide else 1
+        v["hbm_bytes_per_launch"] = fetch + write
+        traffic[display(k)] = int(fetch + write)
+if pmc:
+    json.dump(pmc, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+    json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1, sort_keys=True)
+for k in sorted(pmc):
+    print(k, pmc[k])
