@@ -9,7 +9,8 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libldpc_hip.so")
+# LDPC_HIP_LIB: load another build of the same library (kernel-variant experiments)
+LIB_PATH = os.environ.get("LDPC_HIP_LIB") or os.path.join(_HERE, "libldpc_hip.so")
 _lib = None
 
 

@@ -364,7 +364,7 @@ inline hipError_t layered_run_v(LayeredPlan *pl, const LayeredRun &r, hipStream_
         }
         /* syndrome of this round's bits, freeze (decodeCL.c:393-410) */
         uint64_t *fw = r.failw + (size_t)it * slot;
-        SyndromeArgs sa{r.row_ptr, r.edge_col, r.hard, fw, r.done, pl->M, pl->N};
+        SyndromeArgs sa{r.row_ptr, r.edge_col, r.hard, fw, r.done, pl->M, pl->N, 0, 0};
         dim3 sgrid((pl->M + kBlock - 1) / kBlock, tiles);
         syndrome_kernel<V><<<sgrid, kBlock, 0, s>>>(sa);
         StateArgs st{r.done, fw, r.iters, nullptr, r.frames, it, r.max_iter, r.early_term ? 1 : 0};

@@ -169,6 +169,7 @@ struct ldpc_decoder {
     bool have_last = false;
     int32_t tap_iter = 0;
     int tune_rpw = 0, tune_cpw = 0;     /* LDPC_TUNE_RPW / LDPC_TUNE_CPW: rows / columns per wave */
+    int tune_syn_xcd = 1;               /* LDPC_TUNE_SYN_XCD=0: plain 2-D syndrome grid */
     int32_t last_iterations = 0;
     int64_t last_frames = 0;
     DevBuf<int32_t> summary;            /* [2]: max iters, converged count */
@@ -296,8 +297,10 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
         if (freeze || it == rounds) {
             HIP_TRY(span_begin(d, s, 3));
             uint64_t *fw = d->failw.p + (size_t)it * slot;
-            SyndromeArgs sa{d->row_ptr.p, d->edge_col.p, d->hard.p, fw, d->done.p, d->M, d->N};
-            dim3 sgrid((d->M + kBlock - 1) / kBlock, tiles);
+            const int rbk = (d->M + kBlock - 1) / kBlock;
+            SyndromeArgs sa{d->row_ptr.p, d->edge_col.p, d->hard.p, fw, d->done.p, d->M, d->N,
+                            d->tune_syn_xcd ? tiles : 0, rbk};
+            dim3 sgrid = d->tune_syn_xcd ? dim3(8 * rbk * ((tiles + 7) / 8)) : dim3(rbk, tiles);
             syndrome_kernel<V><<<sgrid, kBlock, 0, s>>>(sa);
             StateArgs st{d->done.p, fw, d->iters.p, nullptr, frames, it, max_iter, 1};
             const bool poll = freeze && it < rounds && d->cfg.poll_interval > 0 &&
@@ -516,6 +519,7 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     const int32_t max_deg = std::max(g->max_row_deg, g->max_col_deg);
     if (const char *e = getenv("LDPC_TUNE_RPW")) d->tune_rpw = atoi(e);
     if (const char *e = getenv("LDPC_TUNE_CPW")) d->tune_cpw = atoi(e);
+    if (const char *e = getenv("LDPC_TUNE_SYN_XCD")) d->tune_syn_xcd = atoi(e);
     d->V = pick_frames_per_lane(*cfg, max_deg);
     d->F = 64 * d->V;
     d->T = (cfg->max_batch + d->F - 1) / d->F;
