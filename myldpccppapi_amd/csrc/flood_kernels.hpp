@@ -187,27 +187,34 @@ __device__ __forceinline__ void check_ms(const float (&x)[D][V], float (&out)[D]
     }
 }
 
-template <int ALGO, int D, int V>
+/* V = frames per lane of the LAYOUT (tile = 64*V frames); W <= V = floats per lane this
+ * kernel moves: a row's 64*V-float segment is covered by V/W waves of 64*W floats each
+ * (consecutive waves of a block).  Narrow waves (W = 1) need fewer registers and run at higher
+ * occupancy: measured 6.0 TB/s against 5.5 TB/s for W = V = 4 on the degree-7 rows. */
+template <int ALGO, int D, int V, int W>
 __global__ __launch_bounds__(kBlock) void check_kernel(const CheckArgs a)
 {
     constexpr size_t F = 64 * V;
+    constexpr int SUB = V / W;
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.y;
     if (tile_finished<V>(a.done, tile)) return;
     const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
-    const int r_begin = wave * a.rows_per_wave;
+    const int sub = wave % SUB;
+    const int r_begin = (wave / SUB) * a.rows_per_wave;
     const int r_end = min(r_begin + a.rows_per_wave, a.n_rows);
-    const float *Qt = a.Q + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
-    float *Rt = a.R + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    const size_t lane_off = (size_t)sub * 64 * W + (size_t)lane * W;
+    const float *Qt = a.Q + (size_t)tile * (size_t)a.E * F + lane_off;
+    float *Rt = a.R + (size_t)tile * (size_t)a.E * F + lane_off;
 
     for (int r = r_begin; r < r_end; ++r) {
         const int e0 = a.cls_e0[r];
-        float x[D][V], out[D][V];
+        float x[D][W], out[D][W];
 #pragma unroll
-        for (int k = 0; k < D; ++k) vload<V>(x[k], Qt + (size_t)(e0 + k) * F);
-        if (ALGO == kAlgoSP) check_sp<D, V>(x, out); else check_ms<D, V>(x, out);
+        for (int k = 0; k < D; ++k) vload<W>(x[k], Qt + (size_t)(e0 + k) * F);
+        if (ALGO == kAlgoSP) check_sp<D, W>(x, out); else check_ms<D, W>(x, out);
 #pragma unroll
-        for (int k = 0; k < D; ++k) vstore<V>(Rt + (size_t)(e0 + k) * F, out[k]);
+        for (int k = 0; k < D; ++k) vstore<W>(Rt + (size_t)(e0 + k) * F, out[k]);
     }
 }
 

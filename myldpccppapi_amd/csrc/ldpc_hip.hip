@@ -100,18 +100,20 @@ namespace {
 using CheckFn = void (*)(const ldpc::CheckArgs);
 using VarFn = void (*)(const ldpc::VarArgs);
 
+/* c: check kernels moving 1 float per lane (narrow waves), cw: V floats per lane */
 template <int ALGO, int V, int D> struct FloodTable {
-    static void fill(CheckFn *c, VarFn *v)
+    static void fill(CheckFn *c, CheckFn *cw, VarFn *v)
     {
-        c[D] = ldpc::check_kernel<ALGO, D, V>;
+        c[D] = ldpc::check_kernel<ALGO, D, V, 1>;
+        cw[D] = ldpc::check_kernel<ALGO, D, V, V>;
         v[D] = ldpc::var_kernel<ALGO, D, V>;
-        FloodTable<ALGO, V, D - 1>::fill(c, v);
+        FloodTable<ALGO, V, D - 1>::fill(c, cw, v);
     }
 };
 template <int ALGO, int V> struct FloodTable<ALGO, V, 0> {
-    static void fill(CheckFn *c, VarFn *v)
+    static void fill(CheckFn *c, CheckFn *cw, VarFn *v)
     {
-        c[0] = ldpc::check_kernel_generic<ALGO, V>;
+        c[0] = cw[0] = ldpc::check_kernel_generic<ALGO, V>;
         v[0] = ldpc::var_kernel_generic<ALGO, V>;
     }
 };
@@ -149,7 +151,8 @@ struct ldpc_decoder {
     DevBuf<int32_t> iters, active;
     std::vector<RowClass> row_classes;
     std::vector<ColClass> col_classes;
-    CheckFn check_fn[ldpc::kMaxUnrolledDegree + 1] = {};
+    CheckFn check_fn[ldpc::kMaxUnrolledDegree + 1] = {};      /* narrow waves (1 float per lane) */
+    CheckFn check_fn_wide[ldpc::kMaxUnrolledDegree + 1] = {}; /* V floats per lane */
     VarFn var_fn[ldpc::kMaxUnrolledDegree + 1] = {};
 
     ldpc::LayeredPlan layered;          /* LDPC_ALGO_LAYERED */
@@ -170,6 +173,7 @@ struct ldpc_decoder {
     int32_t tap_iter = 0;
     int tune_rpw = 0, tune_cpw = 0;     /* LDPC_TUNE_RPW / LDPC_TUNE_CPW: rows / columns per wave */
     int tune_syn_xcd = 1;               /* LDPC_TUNE_SYN_XCD=0: plain 2-D syndrome grid */
+    int tune_check_wide = 0;            /* LDPC_TUNE_CHECK_WIDE=1: check kernels move V floats per lane */
     int32_t last_iterations = 0;
     int64_t last_frames = 0;
     DevBuf<int32_t> summary;            /* [2]: max iters, converged count */
@@ -270,12 +274,13 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
         for (auto &rc : d->row_classes) {
             HIP_TRY(span_begin(d, s, 0, rc.degree, (int64_t)8 * rc.degree * rc.count * frames));
             CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree};
-            const int rpw = d->tune_rpw ? d->tune_rpw : 2;
-            a.rows_per_wave = rpw;
-            const int waves = (rc.count + rpw - 1) / rpw;
-            dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
             const int slotk = rc.degree <= kMaxUnrolledDegree ? rc.degree : 0;
-            d->check_fn[slotk]<<<grid, kBlock, 0, s>>>(a);
+            const bool narrow = slotk && !d->tune_check_wide;
+            const int rpw = d->tune_rpw ? d->tune_rpw : (narrow ? 2 : 1);
+            a.rows_per_wave = rpw;
+            const int waves = ((rc.count + rpw - 1) / rpw) * (narrow ? V : 1);
+            dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
+            (narrow ? d->check_fn : d->check_fn_wide)[slotk]<<<grid, kBlock, 0, s>>>(a);
             HIP_TRY(span_end(d, s));
         }
         /* var_i: bits_i = hard(R_i); Q_i = var(R_i) unless this is the last round */
@@ -284,7 +289,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
                                (int64_t)((it < max_iter ? 8 : 4) * cc.degree + 4) * cc.count * frames));
             VarArgs a{d->R.p, d->Q.p, d->chan.p, d->hard.p, d->done.p, cc.col.p, cc.edge.p,
                       d->E, d->N, cc.count, 1, (it < max_iter) ? 1 : 0, cc.degree};
-            const int cpw = d->tune_cpw ? d->tune_cpw : 2;
+            const int cpw = d->tune_cpw ? d->tune_cpw : 1;
             a.cols_per_wave = cpw;
             const int waves = (cc.count + cpw - 1) / cpw;
             dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
@@ -520,6 +525,7 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     if (const char *e = getenv("LDPC_TUNE_RPW")) d->tune_rpw = atoi(e);
     if (const char *e = getenv("LDPC_TUNE_CPW")) d->tune_cpw = atoi(e);
     if (const char *e = getenv("LDPC_TUNE_SYN_XCD")) d->tune_syn_xcd = atoi(e);
+    if (const char *e = getenv("LDPC_TUNE_CHECK_WIDE")) d->tune_check_wide = atoi(e);
     d->V = pick_frames_per_lane(*cfg, max_deg);
     d->F = 64 * d->V;
     d->T = (cfg->max_batch + d->F - 1) / d->F;
@@ -556,13 +562,13 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
         const bool sp = cfg->algo == LDPC_ALGO_SP;
         constexpr int DM = ldpc::kMaxUnrolledDegree;
         if (sp) {
-            if (d->V == 1) FloodTable<ldpc::kAlgoSP, 1, DM>::fill(d->check_fn, d->var_fn);
-            else if (d->V == 2) FloodTable<ldpc::kAlgoSP, 2, DM>::fill(d->check_fn, d->var_fn);
-            else FloodTable<ldpc::kAlgoSP, 4, DM>::fill(d->check_fn, d->var_fn);
+            if (d->V == 1) FloodTable<ldpc::kAlgoSP, 1, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);
+            else if (d->V == 2) FloodTable<ldpc::kAlgoSP, 2, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);
+            else FloodTable<ldpc::kAlgoSP, 4, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);
         } else {
-            if (d->V == 1) FloodTable<ldpc::kAlgoMS, 1, DM>::fill(d->check_fn, d->var_fn);
-            else if (d->V == 2) FloodTable<ldpc::kAlgoMS, 2, DM>::fill(d->check_fn, d->var_fn);
-            else FloodTable<ldpc::kAlgoMS, 4, DM>::fill(d->check_fn, d->var_fn);
+            if (d->V == 1) FloodTable<ldpc::kAlgoMS, 1, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);
+            else if (d->V == 2) FloodTable<ldpc::kAlgoMS, 2, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);
+            else FloodTable<ldpc::kAlgoMS, 4, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);
         }
     }
     *out = guard.release();
