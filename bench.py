@@ -37,6 +37,80 @@ ITERS = 50
 SIGMA = 0.95
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+# Extra measurement points (BASELINE.json configs[3], configs[4]); NOT the headline line.
+#   python bench.py --config bg1_layered | dvbs2_910_f16
+EXTRA_CONFIGS = {
+    "bg1_layered": dict(desc="5G-NR BG1-profile QC code, Z=384 (N=26112, K=8448, E=121344), batch 8192, "
+                             "layered min-sum fp32, 20 iterations, sigma=1.1 (no frame converges)",
+                        batch=8192, iters=20, sigma=1.1, algo="layered", msg="f32", early=True, poll=0),
+    "dvbs2_910_f16": dict(desc="DVB-S2-profile (64800,58320) rate-9/10 (E=194399, check degree 30), batch 4096, "
+                               "flooding min-sum with fp16 messages, early termination (syndrome) on, "
+                               "max 50 iterations, sigma=0.30",
+                          batch=4096, iters=50, sigma=0.30, algo="ms", msg="f16", early=True, poll=2),
+}
+
+
+def run_extra(name, args):
+    """One JSON line for an extra config (single GPU)."""
+    import myldpccppapi_amd as L
+    from myldpccppapi_amd import codes
+    c = EXTRA_CONFIGS[name]
+    if name == "bg1_layered":
+        Z = 384
+        rows, cols = codes.nr_bg1_profile_edges(Z)
+        N, K, M, layer = 68 * Z, 22 * Z, 46 * Z, Z
+        bytes_fi = 16 * len(rows)
+    else:
+        N, K = 64800, 58320
+        rows, cols = codes.dvbs2_profile_edges(N, K)
+        M, layer = N - K, 0
+        bytes_fi = 8 * len(rows) + 2 * N
+    B = args.batch or c["batch"]
+    if args.sigma:
+        c = dict(c, sigma=args.sigma, desc=c["desc"] + " [sigma override %.3f]" % args.sigma)
+    g = L.Graph(rows, cols, M, N)
+    dec = L.Decoder(g, K, max_batch=B, algo=c["algo"], max_iter=c["iters"], early_term=c["early"],
+                    layer_rows=layer, msg_dtype=c["msg"], poll_interval=c["poll"], frames_per_lane=args.fpl)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(20260101)
+    y = 1.0 + c["sigma"] * torch.randn(B, N, device="cuda", dtype=torch.float32, generator=gen)
+    out = torch.empty(L.out_bytes(K, B), dtype=torch.uint8, device="cuda")
+    it = torch.empty(B, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(args.warmup):
+        dec.decode_device(y.data_ptr(), B, out.data_ptr(), out.numel(), it.data_ptr(), s)
+    torch.cuda.synchronize()
+    dec.set_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dec.decode_device(y.data_ptr(), B, out.data_ptr(), out.numel(), it.data_ptr(), s)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    st = dec.stats()
+    kt = [k for k in dec.kernel_times() if k["phase"] in (0, 1, 2)]
+    iters = it.cpu().numpy()
+    frame_iters = float(iters.sum())
+    kb = sum(k["bytes_total"] for k in kt)
+    kms = sum(k["ms_total"] for k in kt)
+    res = {"metric": "decoded Mbit/s (info bits)", "value": round(B * K / dt / 1e6, 2), "unit": "Mbit/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),
+           "higher_is_better": True, "dtype": "f16" if c["msg"] == "f16" else "f32", "data": "synthetic",
+           "config": {"workload": c["desc"], "frames": B, "rounds_launched": st["iterations_launched"],
+                      "avg_iterations_per_frame": round(frame_iters / B, 2),
+                      "frames_converged": st["frames_converged"],
+                      "bit_errors_in_converged_frames": int(np.unpackbits(out.cpu().numpy().reshape(B, -1)[iters < c["iters"]]).sum())},
+           "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "bytes_per_frame_iteration": bytes_fi,
+                        "message_kernels_achieved": round(kb / (kms * 1e-3) / 1e9, 1),
+                        "message_kernels_frac": round(kb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "whole_step_frac_on_launched_rounds": round(bytes_fi * st["iterations_launched"] * B / dt / 1e9 / HBM_PEAK_GBS, 4),
+                        "per_kernel": {k["name"]: {"avg_ms": round(k["ms_total"] / k["launches"], 4),
+                                                   "GB/s": round(k["bytes_total"] / (k["ms_total"] * 1e-3) / 1e9, 1)}
+                                       for k in sorted(kt, key=lambda k: -k["ms_total"])[:6]}}}
+    print(json.dumps(res), flush=True)
+    dec.close()
+
 
 def cpu_baseline(rows, cols, seconds_budget=20.0):
     """Reference CPU decode (min-sum, MyLdpc.cpp:684-784) via the oracle port, all host
@@ -78,9 +152,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="frames per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the config's)")
+    ap.add_argument("--config", default="dvbs2_sp", choices=["dvbs2_sp"] + sorted(EXTRA_CONFIGS),
+                    help="dvbs2_sp = the headline workload (default); others are extra measurement points")
     ap.add_argument("--algo", default="sp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sigma", type=float, default=0.0, help="extra configs: noise level override")
+    ap.add_argument("--fpl", type=int, default=0, help="frames per lane override (tuning)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,10 +172,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    if args.config != "dvbs2_sp":
+        if world > 1:
+            sys.exit("extra configs are single-GPU measurements")
+        return run_extra(args.config, args)
+
     import myldpccppapi_amd as L
     from myldpccppapi_amd import codes, sharding
 
-    B = args.batch
+    B = args.batch or BATCH_PER_GPU
     rows, cols = codes.dvbs2_profile_edges(N_CODE, K_CODE)
     g = L.Graph(rows, cols, N_CODE - K_CODE, N_CODE)
     dec = L.Decoder(g, K_CODE, max_batch=B, algo=args.algo, max_iter=ITERS, llr_scale=8.0,

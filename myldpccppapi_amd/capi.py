@@ -75,7 +75,7 @@ class Decoder:
         L.ldpc_decoder_config_init(ctypes.byref(cfg))
         cfg.K, cfg.max_batch = int(K), int(max_batch)
         cfg.algo = ALGOS[algo] if isinstance(algo, str) else int(algo)
-        cfg.msg_dtype = msg_dtype
+        cfg.msg_dtype = {"f32": MSG_F32, "f16": MSG_F16}.get(msg_dtype, msg_dtype)
         cfg.max_iter, cfg.llr_scale = int(max_iter), float(llr_scale)
         cfg.early_term, cfg.device, cfg.layer_rows = int(bool(early_term)), int(device), int(layer_rows)
         cfg.pack_mode, cfg.frames_per_lane, cfg.poll_interval = int(pack_mode), int(frames_per_lane), int(poll_interval)

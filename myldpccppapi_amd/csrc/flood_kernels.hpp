@@ -48,7 +48,8 @@ constexpr int kAlgoSP = 0;
 constexpr int kAlgoMS = 1;
 constexpr int kBlock = 256;          /* 4 waves */
 constexpr int kWavesPerBlock = 4;
-constexpr int kMaxUnrolledDegree = 16;
+constexpr int kMaxUnrolledDegree = 16;       /* variable-node kernels, sum-product check kernels */
+constexpr int kMaxUnrolledCheckDegreeMS = 32; /* min-sum check rows: O(D) registers in narrow waves */
 
 /* ---- V-wide per-lane vectors --------------------------------------------- */
 /* Message streams are touched once per kernel (7.4 GB per launch at B = 4096):
@@ -105,6 +106,37 @@ template <> __device__ __forceinline__ void vstore<4>(float *p, const float (&s)
     st_stream(reinterpret_cast<vf4 *>(p), t);
 }
 
+/* fp16 message storage (msg_dtype = LDPC_MSG_F16): 2 bytes per message, arithmetic in fp32.
+ * Loads widen exactly; stores round to nearest even. */
+typedef _Float16 hf;
+typedef _Float16 vh2 __attribute__((ext_vector_type(2)));
+typedef _Float16 vh4 __attribute__((ext_vector_type(4)));
+
+template <int V> __device__ __forceinline__ void vload(float (&d)[V], const hf *p);
+template <> __device__ __forceinline__ void vload<1>(float (&d)[1], const hf *p) { d[0] = (float)ld_stream(p); }
+template <> __device__ __forceinline__ void vload<2>(float (&d)[2], const hf *p)
+{
+    const vh2 t = ld_stream(reinterpret_cast<const vh2 *>(p));
+    d[0] = (float)t.x; d[1] = (float)t.y;
+}
+template <> __device__ __forceinline__ void vload<4>(float (&d)[4], const hf *p)
+{
+    const vh4 t = ld_stream(reinterpret_cast<const vh4 *>(p));
+    d[0] = (float)t.x; d[1] = (float)t.y; d[2] = (float)t.z; d[3] = (float)t.w;
+}
+template <int V> __device__ __forceinline__ void vstore(hf *p, const float (&s)[V]);
+template <> __device__ __forceinline__ void vstore<1>(hf *p, const float (&s)[1]) { st_stream(p, (hf)s[0]); }
+template <> __device__ __forceinline__ void vstore<2>(hf *p, const float (&s)[2])
+{
+    vh2 t; t.x = (hf)s[0]; t.y = (hf)s[1];
+    st_stream(reinterpret_cast<vh2 *>(p), t);
+}
+template <> __device__ __forceinline__ void vstore<4>(hf *p, const float (&s)[4])
+{
+    vh4 t; t.x = (hf)s[0]; t.y = (hf)s[1]; t.z = (hf)s[2]; t.w = (hf)s[3];
+    st_stream(reinterpret_cast<vh4 *>(p), t);
+}
+
 __device__ __forceinline__ int wave_id_in_block()
 {
     return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -123,8 +155,8 @@ template <int V> __device__ __forceinline__ bool tile_finished(const uint64_t *d
 /* ========================================================================= */
 
 struct CheckArgs {
-    const float *__restrict__ Q;         /* [T][E][F] variable->check          */
-    float *__restrict__ R;               /* [T][E][F] check->variable          */
+    const void *__restrict__ Q;          /* [T][E][F] variable->check (float or fp16) */
+    void *__restrict__ R;                /* [T][E][F] check->variable          */
     const int32_t *__restrict__ cls_e0;  /* [n_rows] first edge id of each row of this degree class */
     const uint64_t *__restrict__ done;   /* [T][V] frozen frames                */
     int64_t E;
@@ -191,7 +223,7 @@ __device__ __forceinline__ void check_ms(const float (&x)[D][V], float (&out)[D]
  * kernel moves: a row's 64*V-float segment is covered by V/W waves of 64*W floats each
  * (consecutive waves of a block).  Narrow waves (W = 1) need fewer registers and run at higher
  * occupancy: measured 6.0 TB/s against 5.5 TB/s for W = V = 4 on the degree-7 rows. */
-template <int ALGO, int D, int V, int W>
+template <int ALGO, int D, int V, int W, typename T>
 __global__ __launch_bounds__(kBlock) void check_kernel(const CheckArgs a)
 {
     constexpr size_t F = 64 * V;
@@ -204,8 +236,8 @@ __global__ __launch_bounds__(kBlock) void check_kernel(const CheckArgs a)
     const int r_begin = (wave / SUB) * a.rows_per_wave;
     const int r_end = min(r_begin + a.rows_per_wave, a.n_rows);
     const size_t lane_off = (size_t)sub * 64 * W + (size_t)lane * W;
-    const float *Qt = a.Q + (size_t)tile * (size_t)a.E * F + lane_off;
-    float *Rt = a.R + (size_t)tile * (size_t)a.E * F + lane_off;
+    const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + lane_off;
+    T *Rt = static_cast<T *>(a.R) + (size_t)tile * (size_t)a.E * F + lane_off;
 
     for (int r = r_begin; r < r_end; ++r) {
         const int e0 = a.cls_e0[r];
@@ -218,9 +250,10 @@ __global__ __launch_bounds__(kBlock) void check_kernel(const CheckArgs a)
     }
 }
 
-/* Any degree: re-reads the row per output like the reference does (L1/L2 serve
- * the repeats).  Only used above kMaxUnrolledDegree. */
-template <int ALGO, int V>
+/* Any degree, run-time loops; only used above kMaxUnrolledDegree.  Min-sum: two passes
+ * over the row.  Sum-product: the exact left-to-right product needs one pass per output, as
+ * the reference does (L1/L2 serve the repeats). */
+template <int ALGO, int V, typename T>
 __global__ __launch_bounds__(kBlock) void check_kernel_generic(const CheckArgs a)
 {
     constexpr size_t F = 64 * V;
@@ -231,43 +264,56 @@ __global__ __launch_bounds__(kBlock) void check_kernel_generic(const CheckArgs a
     const int r_begin = wave * a.rows_per_wave;
     const int r_end = min(r_begin + a.rows_per_wave, a.n_rows);
     const int D = a.degree;
-    const float *Qt = a.Q + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
-    float *Rt = a.R + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    T *Rt = static_cast<T *>(a.R) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
     for (int r = r_begin; r < r_end; ++r) {
         const int e0 = a.cls_e0[r];
+        if (ALGO == kAlgoMS) {
+            /* two passes over the row instead of one per output: min1/min2/argmin and the sign
+             * parity first, then each output from its own re-read value (L2 serves the re-read) */
+            float m1[V], m2[V];
+            int idx[V];
+            unsigned par[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) { m1[v] = 1000.0f; m2[v] = 1000.0f; idx[v] = -1; par[v] = 0; }
+            for (int j = 0; j < D; ++j) {
+                float xj[V];
+                vload<V>(xj, Qt + (size_t)(e0 + j) * F);
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float m = __builtin_fabsf(xj[v]);
+                    par[v] ^= (xj[v] < 0.0f) ? 1u : 0u;
+                    if (m < m1[v]) { m2[v] = m1[v]; m1[v] = m; idx[v] = j; }
+                    else if (m < m2[v]) { m2[v] = m; }
+                }
+            }
+            for (int k = 0; k < D; ++k) {
+                float xk[V], o[V];
+                vload<V>(xk, Qt + (size_t)(e0 + k) * F);
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float b = (k == idx[v]) ? m2[v] : m1[v];
+                    const unsigned sg = par[v] ^ ((xk[v] < 0.0f) ? 1u : 0u);
+                    o[v] = sg ? -b : b;
+                }
+                vstore<V>(Rt + (size_t)(e0 + k) * F, o);
+            }
+            continue;
+        }
         for (int k = 0; k < D; ++k) {
             float o[V];
-            if (ALGO == kAlgoSP) {
-                float p[V];
+            float p[V];
 #pragma unroll
-                for (int v = 0; v < V; ++v) p[v] = 1.0f;
-                for (int j = 0; j < D; ++j) {
-                    if (j == k) continue;
-                    float xj[V];
-                    vload<V>(xj, Qt + (size_t)(e0 + j) * F);
+            for (int v = 0; v < V; ++v) p[v] = 1.0f;
+            for (int j = 0; j < D; ++j) {
+                if (j == k) continue;
+                float xj[V];
+                vload<V>(xj, Qt + (size_t)(e0 + j) * F);
 #pragma unroll
-                    for (int v = 0; v < V; ++v) p[v] *= xj[v];
-                }
-#pragma unroll
-                for (int v = 0; v < V; ++v) o[v] = p[v];
-            } else {
-                float b[V];
-                unsigned s[V];
-#pragma unroll
-                for (int v = 0; v < V; ++v) { b[v] = 1000.0f; s[v] = 0; }
-                for (int j = 0; j < D; ++j) {
-                    if (j == k) continue;
-                    float xj[V];
-                    vload<V>(xj, Qt + (size_t)(e0 + j) * F);
-#pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        s[v] ^= (xj[v] < 0.0f) ? 1u : 0u;
-                        b[v] = __builtin_fminf(b[v], __builtin_fabsf(xj[v]));
-                    }
-                }
-#pragma unroll
-                for (int v = 0; v < V; ++v) o[v] = s[v] ? -b[v] : b[v];
+                for (int v = 0; v < V; ++v) p[v] *= xj[v];
             }
+#pragma unroll
+            for (int v = 0; v < V; ++v) o[v] = p[v];
             vstore<V>(Rt + (size_t)(e0 + k) * F, o);
         }
     }
@@ -348,9 +394,9 @@ template <int V> __global__ __launch_bounds__(kBlock) void syndrome_kernel(const
 /* ========================================================================= */
 
 struct VarArgs {
-    const float *__restrict__ R;          /* [T][E][F] */
-    float *__restrict__ Q;                /* [T][E][F] */
-    const float *__restrict__ chan;       /* [T][N][F] SP: exp(scale*y); MS: y */
+    const void *__restrict__ R;           /* [T][E][F] (float or fp16) */
+    void *__restrict__ Q;                 /* [T][E][F] */
+    const void *__restrict__ chan;        /* [T][N][F] SP: exp(scale*y); MS: y */
     uint64_t *hard;                       /* [T][N][V] read-modify-write */
     const uint64_t *__restrict__ done;    /* [T][V] */
     const int32_t *__restrict__ cls_col;  /* [n_cols] column ids of this degree class */
@@ -400,7 +446,7 @@ __device__ __forceinline__ void var_sp(const float (&t)[V], const float (&d)[D][
     }
 }
 
-template <int ALGO, int D, int V>
+template <int ALGO, int D, int V, typename T>
 __global__ __launch_bounds__(kBlock) void var_kernel(const VarArgs a)
 {
     constexpr size_t F = 64 * V;
@@ -410,9 +456,9 @@ __global__ __launch_bounds__(kBlock) void var_kernel(const VarArgs a)
     const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
     const int c_begin = wave * a.cols_per_wave;
     const int c_end = min(c_begin + a.cols_per_wave, a.n_cols);
-    const float *Rt = a.R + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
-    float *Qt = a.Q + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
-    const float *chan_t = a.chan + (size_t)tile * (size_t)a.N * F + (size_t)lane * V;
+    const T *Rt = static_cast<const T *>(a.R) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    T *Qt = static_cast<T *>(a.Q) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    const T *chan_t = static_cast<const T *>(a.chan) + (size_t)tile * (size_t)a.N * F + (size_t)lane * V;
     uint64_t *hard_t = a.hard + (size_t)tile * (size_t)a.N * V;
     uint64_t frozen[V];
 #pragma unroll
@@ -465,7 +511,7 @@ __global__ __launch_bounds__(kBlock) void var_kernel(const VarArgs a)
     }
 }
 
-template <int ALGO, int V>
+template <int ALGO, int V, typename T>
 __global__ __launch_bounds__(kBlock) void var_kernel_generic(const VarArgs a)
 {
     constexpr size_t F = 64 * V;
@@ -476,9 +522,9 @@ __global__ __launch_bounds__(kBlock) void var_kernel_generic(const VarArgs a)
     const int c_begin = wave * a.cols_per_wave;
     const int c_end = min(c_begin + a.cols_per_wave, a.n_cols);
     const int D = a.degree;
-    const float *Rt = a.R + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
-    float *Qt = a.Q + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
-    const float *chan_t = a.chan + (size_t)tile * (size_t)a.N * F + (size_t)lane * V;
+    const T *Rt = static_cast<const T *>(a.R) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    T *Qt = static_cast<T *>(a.Q) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    const T *chan_t = static_cast<const T *>(a.chan) + (size_t)tile * (size_t)a.N * F + (size_t)lane * V;
     uint64_t *hard_t = a.hard + (size_t)tile * (size_t)a.N * V;
     uint64_t frozen[V];
 #pragma unroll
@@ -569,8 +615,8 @@ __global__ __launch_bounds__(kBlock) void var_kernel_generic(const VarArgs a)
 
 struct InitArgs {
     const float *__restrict__ llr;        /* [frames][N] frame-major (reference layout) */
-    float *__restrict__ chan;             /* [T][N][F] */
-    float *__restrict__ Q;                /* [T][E][F] */
+    void *__restrict__ chan;              /* [T][N][F] (float or fp16) */
+    void *__restrict__ Q;                 /* [T][E][F] */
     uint64_t *__restrict__ hard;          /* [T][N][V] */
     const int32_t *__restrict__ col_ptr;  /* [N+1] */
     const int32_t *__restrict__ col_edge; /* [E] */
@@ -586,7 +632,7 @@ struct InitArgs {
  * frames) are contiguous.  Frames past `frames` are filled with y = +1. */
 constexpr int kInitCols = 32;
 
-template <int ALGO, int V>
+template <int ALGO, int V, typename T>
 __global__ __launch_bounds__(kBlock) void init_kernel(const InitArgs a)
 {
     constexpr int F = 64 * V;
@@ -618,13 +664,13 @@ __global__ __launch_bounds__(kBlock) void init_kernel(const InitArgs a)
                 ch[v] = t;
                 q[v] = t / (1.0f + t) - 1.0f / (1.0f + t);          /* :10-11, as q0-q1 */
             } else {
-                ch[v] = y;
+                ch[v] = y;                                          /* fp16 storage rounds it here */
                 q[v] = y;                                           /* :121 */
             }
         }
-        vstore<V>(a.chan + ((size_t)tile * a.N + n) * F + (size_t)lane * V, ch);
+        vstore<V>(static_cast<T *>(a.chan) + ((size_t)tile * a.N + n) * F + (size_t)lane * V, ch);
         for (int p = a.col_ptr[n]; p < a.col_ptr[n + 1]; ++p)
-            vstore<V>(a.Q + ((size_t)tile * (size_t)a.E + (size_t)a.col_edge[p]) * F + (size_t)lane * V, q);
+            vstore<V>(static_cast<T *>(a.Q) + ((size_t)tile * (size_t)a.E + (size_t)a.col_edge[p]) * F + (size_t)lane * V, q);
         if (lane < V) a.hard[((size_t)tile * a.N + n) * V + lane] = 0;
     }
 }

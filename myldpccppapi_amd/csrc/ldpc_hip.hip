@@ -101,22 +101,41 @@ using CheckFn = void (*)(const ldpc::CheckArgs);
 using VarFn = void (*)(const ldpc::VarArgs);
 
 /* c: check kernels moving 1 float per lane (narrow waves), cw: V floats per lane */
-template <int ALGO, int V, int D> struct FloodTable {
+template <int ALGO, int V, typename T, int D> struct FloodTable {
     static void fill(CheckFn *c, CheckFn *cw, VarFn *v)
     {
-        c[D] = ldpc::check_kernel<ALGO, D, V, 1>;
-        cw[D] = ldpc::check_kernel<ALGO, D, V, V>;
-        v[D] = ldpc::var_kernel<ALGO, D, V>;
-        FloodTable<ALGO, V, D - 1>::fill(c, cw, v);
+        c[D] = ldpc::check_kernel<ALGO, D, V, 1, T>;
+        cw[D] = ldpc::check_kernel<ALGO, D, V, V, T>;
+        v[D] = ldpc::var_kernel<ALGO, D, V, T>;
+        FloodTable<ALGO, V, T, D - 1>::fill(c, cw, v);
     }
 };
-template <int ALGO, int V> struct FloodTable<ALGO, V, 0> {
+template <int ALGO, int V, typename T> struct FloodTable<ALGO, V, T, 0> {
     static void fill(CheckFn *c, CheckFn *cw, VarFn *v)
     {
-        c[0] = cw[0] = ldpc::check_kernel_generic<ALGO, V>;
-        v[0] = ldpc::var_kernel_generic<ALGO, V>;
+        c[0] = cw[0] = ldpc::check_kernel_generic<ALGO, V, T>;
+        v[0] = ldpc::var_kernel_generic<ALGO, V, T>;
     }
 };
+
+/* min-sum rows of degree 17..32: narrow unrolled kernels only */
+template <int V, typename T, int D> struct CheckTableMS {
+    static void fill(CheckFn *c, CheckFn *cw)
+    {
+        c[D] = cw[D] = ldpc::check_kernel<ldpc::kAlgoMS, D, V, 1, T>;
+        CheckTableMS<V, T, D - 1>::fill(c, cw);
+    }
+};
+template <int V, typename T> struct CheckTableMS<V, T, ldpc::kMaxUnrolledDegree> {
+    static void fill(CheckFn *, CheckFn *) {}
+};
+
+using InitFn = void (*)(const ldpc::InitArgs);
+template <int ALGO, typename T> InitFn pick_init(int V)
+{
+    return V == 1 ? ldpc::init_kernel<ALGO, 1, T> : V == 2 ? ldpc::init_kernel<ALGO, 2, T>
+                                                         : ldpc::init_kernel<ALGO, 4, T>;
+}
 
 struct RowClass {
     int degree = 0;
@@ -146,13 +165,16 @@ struct ldpc_decoder {
     std::vector<int32_t> h_col_ptr, h_col_edge, h_rows, h_cols;
 
     DevBuf<int32_t> row_ptr, edge_col, col_ptr, col_edge;
-    DevBuf<float> chan, Q, R;
+    DevBuf<uint8_t> chan, Q, R;         /* message arrays: msg_size bytes per element */
+    int msg_size = 4;                   /* 4 = fp32, 2 = fp16 (LDPC_MSG_F16) */
+    InitFn init_fn = nullptr;
     DevBuf<uint64_t> hard, failw, done;
     DevBuf<int32_t> iters, active;
     std::vector<RowClass> row_classes;
     std::vector<ColClass> col_classes;
-    CheckFn check_fn[ldpc::kMaxUnrolledDegree + 1] = {};      /* narrow waves (1 float per lane) */
-    CheckFn check_fn_wide[ldpc::kMaxUnrolledDegree + 1] = {}; /* V floats per lane */
+    CheckFn check_fn[ldpc::kMaxUnrolledCheckDegreeMS + 1] = {};      /* narrow waves (1 value per lane) */
+    CheckFn check_fn_wide[ldpc::kMaxUnrolledCheckDegreeMS + 1] = {}; /* V values per lane */
+    int max_check_unrolled = ldpc::kMaxUnrolledDegree;
     VarFn var_fn[ldpc::kMaxUnrolledDegree + 1] = {};
 
     ldpc::LayeredPlan layered;          /* LDPC_ALGO_LAYERED */
@@ -207,13 +229,17 @@ __global__ void summary_kernel(const int32_t *iters, const uint64_t *done, const
     if ((ok >> l) & 1ull) atomicAdd(&summary[1], 1);
 }
 
-int pick_frames_per_lane(const ldpc_decoder_config &cfg, int32_t max_deg)
+int pick_frames_per_lane(const ldpc_decoder_config &cfg, int32_t max_row_deg, int32_t max_col_deg)
 {
     if (cfg.frames_per_lane) return cfg.frames_per_lane;
-    /* wide tiles (16 B per lane) once there are enough frames to fill them and
-     * the register arrays of the unrolled kernels stay moderate */
-    if (cfg.max_batch >= 1024 && max_deg <= 8) return 4;
-    if (cfg.max_batch >= 256 && max_deg <= ldpc::kMaxUnrolledDegree) return 2;
+    /* Wide tiles (4 values = 16 B fp32 / 8 B fp16 per lane) once there are enough frames to
+     * fill them and the register arrays of the unrolled kernels stay moderate.  Flooding check
+     * kernels run in narrow waves, so only the column degree counts there; the layered kernel
+     * holds a whole row (P and R) per lane. */
+    int deg = cfg.algo == LDPC_ALGO_LAYERED ? max_row_deg : max_col_deg;
+    if (cfg.algo == LDPC_ALGO_MS) deg = (deg + 1) / 2;   /* min-sum variable nodes need half the registers */
+    if (cfg.max_batch >= 1024 && deg <= 8) return 4;
+    if (cfg.max_batch >= 256 && deg <= ldpc::kMaxUnrolledDegree) return 2;
     return 1;
 }
 
@@ -245,9 +271,9 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
                                   hipStream_t s)
 {
     using namespace ldpc;
-    const bool sp = d->cfg.algo == LDPC_ALGO_SP;
     const int F = 64 * V;
     const int tiles = (int)((frames + F - 1) / F);
+    const int64_t msz = d->msg_size;
     const int max_iter = d->cfg.max_iter;
     const int rounds = d->tap_iter ? std::min(d->tap_iter, max_iter) : max_iter;
     const bool freeze = d->cfg.early_term != 0;
@@ -261,8 +287,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
         InitArgs a{llr_dev, d->chan.p, d->Q.p, d->hard.p, d->col_ptr.p, d->col_edge.p,
                    d->E, frames, d->N, d->cfg.llr_scale};
         dim3 grid((d->N + kInitCols - 1) / kInitCols, tiles);
-        if (sp) init_kernel<kAlgoSP, V><<<grid, kBlock, 0, s>>>(a);
-        else init_kernel<kAlgoMS, V><<<grid, kBlock, 0, s>>>(a);
+        d->init_fn<<<grid, kBlock, 0, s>>>(a);
         StateArgs st{d->done.p, nullptr, d->iters.p, nullptr, frames, 0, max_iter, freeze ? 1 : 0};
         state_kernel<V><<<tiles, 64, 0, s>>>(st);
     }
@@ -272,10 +297,10 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
     for (int it = 1; it <= rounds; ++it) {
         /* check_i: R_i = check(Q_{i-1}) */
         for (auto &rc : d->row_classes) {
-            HIP_TRY(span_begin(d, s, 0, rc.degree, (int64_t)8 * rc.degree * rc.count * frames));
+            HIP_TRY(span_begin(d, s, 0, rc.degree, 2 * msz * rc.degree * rc.count * frames));
             CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree};
-            const int slotk = rc.degree <= kMaxUnrolledDegree ? rc.degree : 0;
-            const bool narrow = slotk && !d->tune_check_wide;
+            const int slotk = rc.degree <= d->max_check_unrolled ? rc.degree : 0;
+            const bool narrow = slotk && (!d->tune_check_wide || rc.degree > kMaxUnrolledDegree);
             const int rpw = d->tune_rpw ? d->tune_rpw : (narrow ? 2 : 1);
             a.rows_per_wave = rpw;
             const int waves = ((rc.count + rpw - 1) / rpw) * (narrow ? V : 1);
@@ -286,7 +311,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
         /* var_i: bits_i = hard(R_i); Q_i = var(R_i) unless this is the last round */
         for (auto &cc : d->col_classes) {
             HIP_TRY(span_begin(d, s, 1, cc.degree,
-                               (int64_t)((it < max_iter ? 8 : 4) * cc.degree + 4) * cc.count * frames));
+                               msz * ((it < max_iter ? 2 : 1) * cc.degree + 1) * cc.count * frames));
             VarArgs a{d->R.p, d->Q.p, d->chan.p, d->hard.p, d->done.p, cc.col.p, cc.edge.p,
                       d->E, d->N, cc.count, 1, (it < max_iter) ? 1 : 0, cc.degree};
             const int cpw = d->tune_cpw ? d->tune_cpw : 1;
@@ -503,9 +528,11 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     if (cfg->frames_per_lane != 0 && cfg->frames_per_lane != 1 && cfg->frames_per_lane != 2 &&
         cfg->frames_per_lane != 4)
         return fail(LDPC_ERR_ARG, "frames_per_lane must be 0, 1, 2 or 4");
-    if (cfg->msg_dtype != LDPC_MSG_F32)
-        return fail(LDPC_ERR_UNSUPPORTED, "msg_dtype %d: only fp32 messages are built so far",
-                    cfg->msg_dtype);
+    if (cfg->msg_dtype != LDPC_MSG_F32 && cfg->msg_dtype != LDPC_MSG_F16)
+        return fail(LDPC_ERR_ARG, "unknown msg_dtype %d", cfg->msg_dtype);
+    if (cfg->msg_dtype == LDPC_MSG_F16 && cfg->algo != LDPC_ALGO_MS)
+        return fail(LDPC_ERR_UNSUPPORTED, "fp16 messages are built for flooding min-sum only "
+                    "(the probability-domain SP needs fp32 range; layered: not yet)");
     for (int i = 0; i < 8; ++i)
         if (cfg->reserved[i]) return fail(LDPC_ERR_ARG, "reserved config fields must be 0");
 
@@ -521,12 +548,11 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     d->cfg = *cfg;
     d->M = g->M; d->N = g->N; d->E = g->E;
     d->h_col_ptr = g->col_ptr; d->h_col_edge = g->col_edge; d->h_rows = g->rows; d->h_cols = g->cols;
-    const int32_t max_deg = std::max(g->max_row_deg, g->max_col_deg);
     if (const char *e = getenv("LDPC_TUNE_RPW")) d->tune_rpw = atoi(e);
     if (const char *e = getenv("LDPC_TUNE_CPW")) d->tune_cpw = atoi(e);
     if (const char *e = getenv("LDPC_TUNE_SYN_XCD")) d->tune_syn_xcd = atoi(e);
     if (const char *e = getenv("LDPC_TUNE_CHECK_WIDE")) d->tune_check_wide = atoi(e);
-    d->V = pick_frames_per_lane(*cfg, max_deg);
+    d->V = pick_frames_per_lane(*cfg, g->max_row_deg, g->max_col_deg);
     d->F = 64 * d->V;
     d->T = (cfg->max_batch + d->F - 1) / d->F;
 
@@ -554,22 +580,36 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
         if (rc) return fail(LDPC_ERR_HIP, "layered plan allocation failed: %s",
                             hipGetErrorString(hipGetLastError()));
     } else {
-        HIP_TRY(d->chan.alloc(TF * d->N));
-        HIP_TRY(d->Q.alloc(TF * (size_t)d->E));
-        HIP_TRY(d->R.alloc(TF * (size_t)d->E));
+        d->msg_size = cfg->msg_dtype == LDPC_MSG_F16 ? 2 : 4;
+        HIP_TRY(d->chan.alloc(TF * d->N * d->msg_size));
+        HIP_TRY(d->Q.alloc(TF * (size_t)d->E * d->msg_size));
+        HIP_TRY(d->R.alloc(TF * (size_t)d->E * d->msg_size));
         int rc = build_classes(d, g);
         if (rc) return rc;
-        const bool sp = cfg->algo == LDPC_ALGO_SP;
         constexpr int DM = ldpc::kMaxUnrolledDegree;
-        if (sp) {
-            if (d->V == 1) FloodTable<ldpc::kAlgoSP, 1, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);
-            else if (d->V == 2) FloodTable<ldpc::kAlgoSP, 2, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);
-            else FloodTable<ldpc::kAlgoSP, 4, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);
-        } else {
-            if (d->V == 1) FloodTable<ldpc::kAlgoMS, 1, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);
-            else if (d->V == 2) FloodTable<ldpc::kAlgoMS, 2, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);
-            else FloodTable<ldpc::kAlgoMS, 4, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);
-        }
+        using ldpc::kAlgoMS;
+        using ldpc::kAlgoSP;
+        using ldpc::hf;
+#define LDPC_FILL(ALGO, TYPE)                                                                          \
+    do {                                                                                               \
+        if (d->V == 1) FloodTable<ALGO, 1, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);  \
+        else if (d->V == 2) FloodTable<ALGO, 2, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn); \
+        else FloodTable<ALGO, 4, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);            \
+        d->init_fn = pick_init<ALGO, TYPE>(d->V);                                                      \
+    } while (0)
+#define LDPC_FILL_MS_HIGH(TYPE)                                                                         \
+    do {                                                                                               \
+        constexpr int DH = ldpc::kMaxUnrolledCheckDegreeMS;                                            \
+        if (d->V == 1) CheckTableMS<1, TYPE, DH>::fill(d->check_fn, d->check_fn_wide);                 \
+        else if (d->V == 2) CheckTableMS<2, TYPE, DH>::fill(d->check_fn, d->check_fn_wide);            \
+        else CheckTableMS<4, TYPE, DH>::fill(d->check_fn, d->check_fn_wide);                           \
+        d->max_check_unrolled = DH;                                                                    \
+    } while (0)
+        if (cfg->algo == LDPC_ALGO_SP) LDPC_FILL(kAlgoSP, float);
+        else if (cfg->msg_dtype == LDPC_MSG_F16) { LDPC_FILL(kAlgoMS, hf); LDPC_FILL_MS_HIGH(hf); }
+        else { LDPC_FILL(kAlgoMS, float); LDPC_FILL_MS_HIGH(float); }
+#undef LDPC_FILL
+#undef LDPC_FILL_MS_HIGH
     }
     *out = guard.release();
     return LDPC_OK;
@@ -716,7 +756,9 @@ int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t ca
     HIP_TRY(hipSetDevice(d->cfg.device));
     HIP_TRY(hipEventSynchronize(d->ev_end));
     static const char *phase_name[] = {"check_kernel", "var_kernel", "layer_kernel", "other"};
-    static const char *algo_name[] = {"sp", "ms", "layered"};
+    static const char *algo_name_f32[] = {"sp", "ms", "layered"};
+    static const char *algo_name_f16[] = {"sp16", "ms16", "layered16"};
+    const char **algo_name = d->msg_size == 2 ? algo_name_f16 : algo_name_f32;
     for (size_t i = 0; i < d->spans_used; ++i) {
         const TimedSpan &sp = d->spans[i];
         float ms = 0;
@@ -768,15 +810,23 @@ int ldpc_decoder_dump(ldpc_decoder *d, int32_t which, float *host_out, int64_t c
     if (which == 0 || which == 1 || which == 2) {
         const int64_t per = (which == 2) ? d->N : d->E;
         if (count != frames * per) return fail(LDPC_ERR_ARG, "count must be frames*%lld", (long long)per);
-        const float *src = which == 0 ? d->R.p : (which == 1 ? d->Q.p : d->chan.p);
-        std::vector<float> tile((size_t)per * F);
+        const uint8_t *src = which == 0 ? d->R.p : (which == 1 ? d->Q.p : d->chan.p);
+        const size_t esz = (size_t)d->msg_size;
+        std::vector<uint8_t> tile((size_t)per * F * esz);
         for (int t = 0; t < tiles; ++t) {
-            HIP_TRY(hipMemcpy(tile.data(), src + (size_t)t * per * F, tile.size() * sizeof(float),
-                              hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(tile.data(), src + (size_t)t * per * F * esz, tile.size(), hipMemcpyDeviceToHost));
             for (int fi = 0; fi < F; ++fi) {
                 const int64_t f = (int64_t)t * F + fi;
                 if (f >= frames) break;
-                for (int64_t i = 0; i < per; ++i) host_out[f * per + i] = tile[(size_t)i * F + fi];
+                for (int64_t i = 0; i < per; ++i) {
+                    if (esz == 4) {
+                        memcpy(&host_out[f * per + i], &tile[((size_t)i * F + fi) * 4], 4);
+                    } else {
+                        _Float16 h;
+                        memcpy(&h, &tile[((size_t)i * F + fi) * 2], 2);
+                        host_out[f * per + i] = (float)h;
+                    }
+                }
             }
         }
         return LDPC_OK;

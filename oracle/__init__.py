@@ -52,7 +52,7 @@ def lib():
         common = [ctypes.POINTER(_Graph)]
         tail = [ctypes.c_int, _u8p, ctypes.c_int64, _i32p, _u8p, ctypes.POINTER(_Taps)]
         L.oracle_decode_ms.restype = ctypes.c_int
-        L.oracle_decode_ms.argtypes = common + [_f32p, ctypes.c_int64, ctypes.c_int] + tail
+        L.oracle_decode_ms.argtypes = common + [_f32p, ctypes.c_int64, ctypes.c_int] + tail + [ctypes.c_int]
         L.oracle_decode_sp.restype = ctypes.c_int
         L.oracle_decode_sp.argtypes = common + [_f32p, ctypes.c_int64, ctypes.c_int,
                                                 ctypes.c_float] + tail
@@ -110,7 +110,7 @@ def out_len(frames, K, pack_mode=0):
     return (frames * K + 7) // 8
 
 
-def decode(g, y, algo, max_iter=40, llr_scale=8.0, pack_mode=0, layer_rows=0, tap_iter=0):
+def decode(g, y, algo, max_iter=40, llr_scale=8.0, pack_mode=0, layer_rows=0, tap_iter=0, msg_f16=False):
     """Run one oracle decoder.  algo in {"ms", "sp", "layered"}.
 
     Returns dict(out=bytes array, iters=int32[frames], hard=uint8[frames,N],
@@ -134,7 +134,7 @@ def decode(g, y, algo, max_iter=40, llr_scale=8.0, pack_mode=0, layer_rows=0, ta
     tp = ctypes.byref(ctaps) if ctaps is not None else None
     tail = (pack_mode, _p(out, _u8p), out.size, _p(iters, _i32p), _p(hard, _u8p), tp)
     if algo == "ms":
-        rc = L.oracle_decode_ms(ctypes.byref(g._c), _p(y, _f32p), frames, max_iter, *tail)
+        rc = L.oracle_decode_ms(ctypes.byref(g._c), _p(y, _f32p), frames, max_iter, *tail, int(msg_f16))
     elif algo == "sp":
         rc = L.oracle_decode_sp(ctypes.byref(g._c), _p(y, _f32p), frames, max_iter,
                                 ctypes.c_float(llr_scale), *tail)

@@ -140,9 +140,40 @@ static void tap_copy(float *dst, int64_t frame, int64_t n, const float *src)
 
 /* ------------------------------------------------------- min-sum flooding */
 
+/* IEEE binary16 round trip (round to nearest even), for the fp16-message mode.  That mode
+ * is this repository's own extension (the reference has fp32 only): channel values and
+ * variable->check messages are rounded to binary16 when stored, all arithmetic stays fp32;
+ * check->variable messages are minima of stored values (or 1000) and need no rounding. */
+static float f16_round(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint32_t sign = u & 0x80000000u;
+    uint32_t a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return x;                      /* inf, NaN */
+    if (a < 0x38800000u) {                               /* |x| < 2^-14: binary16 subnormal grid 2^-24 */
+        float ax;
+        memcpy(&ax, &a, 4);
+        ax = (ax + 0.5f) - 0.5f;                         /* ulp(0.5) = 2^-24, RNE */
+        memcpy(&a, &ax, 4);
+    } else {
+        a += 0xfffu + ((a >> 13) & 1u);                  /* RNE at 10 mantissa bits */
+        a &= ~0x1fffu;
+        if (a >= 0x47800000u) a = 0x7f800000u;           /* >= 65520 rounds to infinity */
+    }
+    a |= sign;
+    memcpy(&x, &a, 4);
+    return x;
+}
+
+void oracle_f16_round(const float *in, float *out, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = f16_round(in[i]);
+}
+
 int oracle_decode_ms(const oracle_graph *g, const float *y, int64_t frames,
                      int max_iter, int pack_mode, uint8_t *out, int64_t out_bytes,
-                     int32_t *iters, uint8_t *hard_out, const oracle_taps *taps)
+                     int32_t *iters, uint8_t *hard_out, const oracle_taps *taps, int msg_f16)
 {
     const int64_t E = g->E;
     const int32_t N = g->N;
@@ -152,8 +183,15 @@ int oracle_decode_ms(const oracle_graph *g, const float *y, int64_t frames,
     uint8_t *src = (uint8_t *)calloc((size_t)N, 1);
     if (!lQ || !lR || !lPostP || !src) return -2;
 
+    float *y16 = msg_f16 ? (float *)malloc(sizeof(float) * (size_t)N) : NULL;
+    if (msg_f16 && !y16) return -2;
+
     for (int64_t f = 0; f < frames; ++f) {
         const float *yf = y + f * N;
+        if (msg_f16) {
+            for (int32_t n = 0; n < N; ++n) y16[n] = f16_round(yf[n]);
+            yf = y16;
+        }
         int time = 0;
         /* decodeInitMS, decodeCL.c:113-124 (MyLdpc.cpp:697-702 keeps the same
          * value split into sign and magnitude) */
@@ -188,14 +226,17 @@ int oracle_decode_ms(const oracle_graph *g, const float *y, int64_t frames,
             if (!flag) break;              /* MyLdpc.cpp:751-755, 824-833 */
             if (time == max_iter) break;
             /* refreshQMS, decodeCL.c:175-186 / MyLdpc.cpp:757-762 */
-            for (int64_t e = 0; e < E; ++e) lQ[e] = lPostP[g->cols[e]] - lR[e];
+            for (int64_t e = 0; e < E; ++e) {
+                lQ[e] = lPostP[g->cols[e]] - lR[e];
+                if (msg_f16) lQ[e] = f16_round(lQ[e]);
+            }
             if (taps && taps->iter == time) tap_copy(taps->q, f, E, lQ);
         }
         if (iters) iters[f] = time;
         if (hard_out) memcpy(hard_out + f * N, src, (size_t)N);
         pack_frame(g, src, f, pack_mode, out, out_bytes);
     }
-    free(lQ); free(lR); free(lPostP); free(src);
+    free(lQ); free(lR); free(lPostP); free(src); free(y16);
     return 0;
 }
 

@@ -77,10 +77,16 @@ typedef struct {
 /* Min-sum flooding: decodeCPU MyLdpc.cpp:684-784 == decodeOnceMS
  * MyLdpc.cpp:786-848 + kernels decodeCL.c:113-186,88-108.  iters[frame] =
  * iteration at which the syndrome first became clean, else max_iter.
- * hard_out (nullable): [frames][N] hard bits, one byte each. */
+ * hard_out (nullable): [frames][N] hard bits, one byte each.
+ * msg_f16 != 0: this repository's fp16-message extension (not in the reference):
+ * channel values and variable->check messages are rounded to IEEE binary16 when
+ * stored, arithmetic stays fp32.  Parity for that mode is vs this definition only. */
 int oracle_decode_ms(const oracle_graph *g, const float *y, int64_t frames,
                      int max_iter, int pack_mode, uint8_t *out, int64_t out_bytes,
-                     int32_t *iters, uint8_t *hard_out, const oracle_taps *taps);
+                     int32_t *iters, uint8_t *hard_out, const oracle_taps *taps, int msg_f16);
+
+/* The binary16 round trip used by msg_f16 (exposed for its own test). */
+void oracle_f16_round(const float *in, float *out, int64_t n);
 
 /* Sum-product flooding, probability domain: decodeOnceSP MyLdpc.cpp:977-1059 +
  * kernels decodeCL.c:3-108.  llr_scale is the reference's hard-coded 8

@@ -100,13 +100,14 @@ def test_high_rate_check_degree_30(built):
     g = L.Graph(rows, cols, N2 - K2, N2)
     og = oracle.Graph(rows, cols, N2 - K2, N2, K2)
     y = channel.awgn_frames(N2, 0, 66, 0.36, seed=51)
-    dec = L.Decoder(g, K2, max_batch=66, algo="ms", max_iter=30)
-    out, iters = dec.decode(y)
-    o = oracle.decode(og, y[[0, 65]], "ms", max_iter=30)
     kb = K2 // 8
-    assert np.array_equal(out[:kb], o["out"][:kb]) and np.array_equal(out[65 * kb:], o["out"][kb:])
-    assert iters[0] == o["iters"][0] and iters[65] == o["iters"][1]
-    dec.close()
+    for f16 in (False, True):        # configs[4] stores messages in fp16
+        dec = L.Decoder(g, K2, max_batch=66, algo="ms", max_iter=30, msg_dtype="f16" if f16 else "f32")
+        out, iters = dec.decode(y)
+        o = oracle.decode(og, y[[0, 65]], "ms", max_iter=30, msg_f16=f16)
+        assert np.array_equal(out[:kb], o["out"][:kb]) and np.array_equal(out[65 * kb:], o["out"][kb:])
+        assert iters[0] == o["iters"][0] and iters[65] == o["iters"][1]
+        dec.close()
 
 
 def test_layered_bg1_profile_z384(built):

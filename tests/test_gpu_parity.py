@@ -167,6 +167,31 @@ def test_early_termination_switch_and_polling(built):
     dec.close()
 
 
+@pytest.mark.parametrize("V", [1, 2, 4])
+def test_fp16_messages_follow_their_definition(built, V):
+    """msg_dtype = f16 (this repository's extension; the reference is fp32 only): channel
+    values and variable->check messages are rounded to binary16 when stored, arithmetic is
+    fp32.  The HIP path must equal that definition (oracle msg_f16) bit for bit."""
+    for rate, N, sigma, B in ((0, 648, 0.8, 9), (4, 576, 0.5, 70), (5, 1152, 0.42, 20), (0, 2304, 0.9, 5)):
+        g, og, K, M, z = _graph(rate, N)
+        y = channel.awgn_frames(N, 0, B, sigma, seed=12)
+        dec = L.Decoder(g, K, max_batch=B, algo="ms", msg_dtype="f16", frames_per_lane=V)
+        out, iters = dec.decode(y)
+        want = oracle.decode(og, y, "ms", msg_f16=True, tap_iter=2)
+        assert np.array_equal(out, want["out"]) and np.array_equal(iters, want["iters"]), (rate, N)
+        dec.set_tap(2)
+        dec.decode(y)
+        run_r = np.nonzero(want["iters"] >= 2)[0]
+        run_q = np.nonzero(want["iters"] > 2)[0]
+        assert np.array_equal(dec.dump(0, B)[run_r], want["taps"]["r"][run_r])
+        assert np.array_equal(dec.dump(1, B)[run_q], want["taps"]["q"][run_q])
+        assert np.array_equal(dec.dump(2, B), y.astype(np.float16).astype(np.float32))
+        dec.close()
+    with pytest.raises(L.LdpcError) as e:
+        L.Decoder(g, K, 8, algo="sp", msg_dtype="f16")
+    assert e.value.code == 4
+
+
 def test_generic_degree_kernels(built):
     """Degrees above the unrolled range take the generic kernels: the rate-5/6 seed has
     row weight 20 (flooding check / layered rows)."""

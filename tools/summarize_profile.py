@@ -29,9 +29,10 @@ def short(name):
 
 def display(name):
     """check_kernel<0, 7, 4> -> check_kernel<sp,7,4> (the names bench.py prints)"""
-    m = re.match(r"(check_kernel|var_kernel)<(\d), (\d+), (\d)>", name)
+    m = re.match(r"(check_kernel|var_kernel)<(\d), (\d+), (\d)(?:, \d)?, (float|_Float16)>", name)
     if m:
-        return "%s<%s,%s,%s>" % (m.group(1), ("sp", "ms")[int(m.group(2))], m.group(3), m.group(4))
+        algo = ("sp", "ms")[int(m.group(2))] + ("16" if m.group(5) != "float" else "")
+        return "%s<%s,%s,%s>" % (m.group(1), algo, m.group(3), m.group(4))
     m = re.match(r"layer_kernel<(\d+), (\d)>", name)
     if m:
         return "layer_kernel<layered,%s,%s>" % (m.group(1), m.group(2))
@@ -69,7 +70,8 @@ for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
 traffic = {}
 for k, v in pmc.items():
     if "FETCH_SIZE_KiB_per_launch" in v and "WRITE_SIZE_KiB_per_launch" in v:
-        wide = bool(re.search(r"(check_kernel|var_kernel|layer_kernel)<.*4>$", k))
+        # 16 B per lane streams: var/layer kernels at V = 4 (fp32); the narrow check kernels move 4 B per lane
+        wide = bool(re.search(r"(var_kernel<\d, \d+, 4, float>|layer_kernel<\d+, 4>|check_kernel<\d, \d+, 4, 4, float>)$", k))
         fetch = v["FETCH_SIZE_KiB_per_launch"] * 1024 * (2 if wide else 1)
         write = v["WRITE_SIZE_KiB_per_launch"] * 1024
         v["fetch_correction"] = 2 if wide else 1
