@@ -157,6 +157,8 @@ def main():
                     help="dvbs2_sp = the headline workload (default); others are extra measurement points")
     ap.add_argument("--algo", default="sp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N > 1 flow on fewer GPUs than ranks (collectives on CPU copies)")
     ap.add_argument("--sigma", type=float, default=0.0, help="extra configs: noise level override")
     ap.add_argument("--fpl", type=int, default=0, help="frames per lane override (tuning)")
     args = ap.parse_args()
@@ -167,10 +169,16 @@ def main():
     if world != max(args.gpus, 1):
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    rehearsal = args.backend == "gloo"
+    if rehearsal:
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     if args.config != "dvbs2_sp":
         if world > 1:
@@ -196,8 +204,12 @@ def main():
     def step():
         s = torch.cuda.current_stream().cuda_stream
         dec.decode_device(y.data_ptr(), B, out.data_ptr(), out.numel(), None, s)
-        if world > 1:
+        if world > 1 and not rehearsal:
             dist.all_gather_into_tensor(gathered, out)     # the only collective: decoded bytes
+        elif world > 1:
+            parts = [torch.empty(out.numel(), dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(parts, out.cpu())
+            gathered.copy_(torch.cat(parts))
 
     def fence():
         if world > 1:
@@ -215,7 +227,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
