@@ -1,0 +1,292 @@
+/*
+ * fused_kernels.hpp -- whole-decode-in-one-launch layered min-sum for SHORT quasi-cyclic
+ * codes: the MI355X counterpart of the reference's fused kernel decodeOnceTDMP
+ * (decodeCL.c:307-426, launched by Coder::decodeOnceTDMPCL, MyLdpc.cpp:850-868).
+ *
+ * For codes of a few thousand bits, streaming the messages through HBM once per layer
+ * launch (layered_kernels.hpp) is the wrong design: a frame's whole state -- posteriors
+ * P[N] and messages R[E], (N+E)*4 B = 9.6 KB at N = 576, 38 KB at N = 2304 -- fits in LDS
+ * (160 KB per CU).  So, like the reference, one frame is decoded start to finish by one
+ * group of lanes with its state on chip, and the launch count drops from
+ * layers*iterations to one.  Unlike the reference:
+ *   - the lanes of a wave are the z rows of the current layer, so P is read and written at
+ *     consecutive LDS addresses (column = block*z + (row + shift) mod z): conflict-free;
+ *     R is kept layer-major [layer][k][row] for the same reason (the reference keeps R in
+ *     private arrays indexed [12][24] and rebuilds a column table per work-item);
+ *   - the circulant structure is DETECTED from the edge list (any QC code, not only the
+ *     802.16e seeds; any z, not z <= 127 / N <= 32767) and held as a small table of
+ *     (block column, shift) pairs that every lane reads through the scalar cache;
+ *   - codes with z <= 64 need no barrier at all: one 64-lane wave owns one frame (LDS
+ *     operations of a wave are ordered); larger z use ceil(z/64) waves per frame and
+ *     workgroup barriers between layers; several frames share a CU's LDS (4 at N = 2304);
+ *   - the missing barrier after the posterior fill and the uninitialised `bInd` of the
+ *     reference kernel do not exist here.
+ * Arithmetic and results are those of layer_kernel / the oracle's layered decoder, bit for
+ * bit (same fp32 operations in the same order).
+ */
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "layered_kernels.hpp"
+
+namespace ldpc {
+
+struct FusedArgs {
+    const float *__restrict__ llr;        /* [frames][N] frame-major, as the caller gives it */
+    uint8_t *__restrict__ out;            /* packed bytes, toChar layout */
+    int32_t *__restrict__ iters;          /* [frames] or nullptr */
+    int32_t *__restrict__ summary;        /* [2]: max iters, converged frames */
+    float *__restrict__ dump_p;           /* [frames][N] or nullptr (taps) */
+    float *__restrict__ dump_r;           /* [frames][E] reference edge order, or nullptr */
+    uint8_t *__restrict__ conv;           /* [frames] 1 = syndrome clean, or nullptr */
+    const int32_t *__restrict__ layer_ptr;/* [layers+1] into the entry tables */
+    const int32_t *__restrict__ ent_bc;   /* block column of entry */
+    const int32_t *__restrict__ ent_sh;   /* circulant shift of entry */
+    const int32_t *__restrict__ layer_e0; /* [layers] edge id of the layer's first edge */
+    int64_t frames, out_bytes;
+    int32_t N, E, K, z, layers, max_iter, rounds, early_term;
+};
+
+/* One workgroup = one frame = MW waves (MW = ceil(z/64)); MW == 1 needs no barriers. */
+template <int MW>
+__global__ __launch_bounds__(64 * MW) void fused_layered_kernel(const FusedArgs a)
+{
+    extern __shared__ float lds[];
+    const int lane_in_frame = (int)threadIdx.x;
+    const int64_t frame = (int64_t)blockIdx.x;
+    float *P = lds;
+    float *R = P + a.N;
+    constexpr int LANES = 64 * MW;
+    const int z = a.z;
+    const int r = lane_in_frame;               /* row inside the layer */
+
+    /* MW == 1: a wave's LDS operations execute in program order, so other lanes' earlier
+     * writes are visible to later reads; the fence only stops the compiler from reordering. */
+    auto sync = [&]() {
+        if (MW == 1) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __syncthreads();
+        }
+    };
+
+    /* lP = postCode, lR = 0 (decodeCL.c:331-340) */
+    const float *y = a.llr + (size_t)frame * a.N;
+    for (int n = lane_in_frame; n < a.N; n += LANES) P[n] = y[n];
+    for (int e = lane_in_frame; e < a.E; e += LANES) R[e] = 0.0f;
+    sync();
+
+    int time = 0;
+    bool clean = false;
+    while (true) {
+        for (int l = 0; l < a.layers; ++l) {
+            const int p0 = a.layer_ptr[l], d = a.layer_ptr[l + 1] - p0;
+            float *Rl = R + a.layer_e0[l];              /* [d][z] */
+            if (r < z) {
+                float prod = 1.0f, b = 1000.0f, c = 1001.0f;   /* decodeCL.c:346-348 */
+                int bind = -1;
+                for (int k = 0; k < d; ++k) {                  /* :350-367 */
+                    int t = r + a.ent_sh[p0 + k];
+                    t = t >= z ? t - z : t;
+                    const int col = a.ent_bc[p0 + k] * z + t;
+                    const float q = P[col] - Rl[k * z + r];
+                    prod *= q;
+                    P[col] = q;                                /* :357 parks q in lP */
+                    const float mag = __builtin_fabsf(q);
+                    if (mag <= b) { c = b; b = mag; bind = k; }
+                    else if (mag > b && mag <= c) { c = mag; }
+                }
+                const float sa = cl_sign(prod);                /* :369 */
+                const float ab = sa * b, ac = sa * c;
+                for (int k = 0; k < d; ++k) {                  /* :371-383 */
+                    int t = r + a.ent_sh[p0 + k];
+                    t = t >= z ? t - z : t;
+                    const int col = a.ent_bc[p0 + k] * z + t;
+                    const float q = P[col];
+                    const float rn = cl_sign(q) * ((k == bind) ? ac : ab);
+                    Rl[k * z + r] = rn;
+                    P[col] = q + rn;
+                }
+            }
+            sync();                                            /* :385 */
+        }
+        /* bits = P < 0, row parities (decodeCL.c:387-404) */
+        int bad = 0;
+        if (r < z) {
+            for (int l = 0; l < a.layers; ++l) {
+                const int p0 = a.layer_ptr[l], d = a.layer_ptr[l + 1] - p0;
+                int par = 0;
+                for (int k = 0; k < d; ++k) {
+                    int t = r + a.ent_sh[p0 + k];
+                    t = t >= z ? t - z : t;
+                    par ^= (P[a.ent_bc[p0 + k] * z + t] < 0.0f) ? 1 : 0;
+                }
+                bad |= par;
+            }
+        }
+        const int any_bad = (MW == 1) ? (__ballot(bad != 0) != 0ull) : __syncthreads_or(bad);
+        ++time;
+        clean = !any_bad;
+        if ((clean && a.early_term) || time == a.rounds) break; /* :407-410 */
+        sync();
+    }
+    sync();
+
+    /* toChar (decodeCL.c:414-423): byte j = bits 8j..8j+7 of the first K */
+    const int64_t base = frame * (int64_t)a.K / 8;
+    for (int j = lane_in_frame; j < a.K / 8; j += LANES) {
+        unsigned byte = 0;
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) byte |= (P[j * 8 + bit] < 0.0f ? 1u : 0u) << bit;
+        if (base + j < a.out_bytes) a.out[base + j] = (uint8_t)byte;
+    }
+    if (a.dump_p)
+        for (int n = lane_in_frame; n < a.N; n += LANES) a.dump_p[(size_t)frame * a.N + n] = P[n];
+    if (a.dump_r) {
+        /* back to the reference's row-major edge order: edge (layer l, row r, k) */
+        for (int l = 0; l < a.layers; ++l) {
+            const int d = a.layer_ptr[l + 1] - a.layer_ptr[l], e0 = a.layer_e0[l];
+            for (int i = lane_in_frame; i < d * z; i += LANES) {
+                const int rr = i / d, k = i % d;
+                a.dump_r[(size_t)frame * a.E + e0 + i] = R[e0 + k * z + rr];
+            }
+        }
+    }
+    if (lane_in_frame == 0) {
+        /* iters: first clean iteration, else max_iter (a frame clean only at the cap counts as
+         * converged at `time`, like state_kernel) */
+        const int it = clean ? time : a.max_iter;
+        if (a.iters) a.iters[frame] = it;
+        if (a.conv) a.conv[frame] = clean ? 1 : 0;
+        atomicMax(&a.summary[0], it);
+        if (clean) atomicAdd(&a.summary[1], 1);
+    }
+}
+
+/* ---------------------------------------------------------------- host side */
+
+struct FusedPlan {
+    bool eligible = false;
+    int32_t z = 0, layers = 0, N = 0, E = 0, M = 0;
+    int32_t *layer_ptr = nullptr, *ent_bc = nullptr, *ent_sh = nullptr, *layer_e0 = nullptr; /* device */
+    float *dump_p = nullptr, *dump_r = nullptr;
+    uint8_t *conv = nullptr;
+    int64_t dump_frames = 0;
+    size_t lds_per_frame = 0;
+};
+
+inline void fused_plan_destroy(FusedPlan *pl)
+{
+    for (void *p : {(void *)pl->layer_ptr, (void *)pl->ent_bc, (void *)pl->ent_sh, (void *)pl->layer_e0,
+                    (void *)pl->dump_p, (void *)pl->dump_r, (void *)pl->conv})
+        if (p) (void)hipFree(p);
+    *pl = FusedPlan();
+}
+
+/* Detect the circulant structure of every layer: all z rows of a layer have the same
+ * degree and row r's k-th edge sits in column bc_k*z + (r + s_k) mod z.  Returns true and
+ * fills the host tables when the whole matrix has that form. */
+inline bool fused_detect_qc(int32_t M, int32_t N, const std::vector<int32_t> &row_ptr,
+                            const std::vector<int32_t> &cols, int32_t z, std::vector<int32_t> &layer_ptr,
+                            std::vector<int32_t> &bc, std::vector<int32_t> &sh, std::vector<int32_t> &e0)
+{
+    if (z <= 0 || M % z || N % z) return false;
+    const int layers = M / z;
+    layer_ptr.assign(1, 0);
+    bc.clear(); sh.clear(); e0.clear();
+    for (int l = 0; l < layers; ++l) {
+        const int m0 = l * z, d = row_ptr[m0 + 1] - row_ptr[m0];
+        if (d <= 0) return false;
+        e0.push_back(row_ptr[m0]);
+        for (int k = 0; k < d; ++k) {
+            const int c = cols[row_ptr[m0] + k];
+            bc.push_back(c / z);
+            sh.push_back(c % z);
+        }
+        for (int r = 1; r < z; ++r) {
+            const int m = m0 + r;
+            if (row_ptr[m + 1] - row_ptr[m] != d) return false;
+            for (int k = 0; k < d; ++k) {
+                const int want = bc[layer_ptr[l] + k] * z + (r + sh[layer_ptr[l] + k]) % z;
+                if (cols[row_ptr[m] + k] != want) return false;
+            }
+        }
+        /* row-major order inside a row = ascending block column; a block column may appear once */
+        for (int k = 1; k < d; ++k)
+            if (bc[layer_ptr[l] + k] <= bc[layer_ptr[l] + k - 1]) return false;
+        layer_ptr.push_back(layer_ptr[l] + d);
+    }
+    return true;
+}
+
+constexpr size_t kFusedMaxLdsPerFrame = 48 * 1024;   /* >= 3 frames per CU (160 KB LDS) */
+
+inline hipError_t fused_plan_create(FusedPlan *pl, int32_t M, int32_t N, int64_t E,
+                                    const std::vector<int32_t> &row_ptr, const std::vector<int32_t> &cols,
+                                    int32_t z)
+{
+    std::vector<int32_t> lp, bc, sh, e0;
+    pl->eligible = false;
+    if (z > 256 || (size_t)(N + E) * 4 > kFusedMaxLdsPerFrame) return hipSuccess;
+    if (!fused_detect_qc(M, N, row_ptr, cols, z, lp, bc, sh, e0)) return hipSuccess;
+    pl->z = z; pl->layers = M / z; pl->N = N; pl->E = (int32_t)E; pl->M = M;
+    pl->lds_per_frame = (size_t)(N + E) * 4;
+    auto up = [](int32_t **dst, const std::vector<int32_t> &v) {
+        hipError_t e = hipMalloc((void **)dst, v.size() * sizeof(int32_t));
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*dst, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    };
+    hipError_t e;
+    if ((e = up(&pl->layer_ptr, lp)) || (e = up(&pl->ent_bc, bc)) || (e = up(&pl->ent_sh, sh)) ||
+        (e = up(&pl->layer_e0, e0)))
+        return e;
+    pl->eligible = true;
+    return hipSuccess;
+}
+
+struct FusedRun {
+    const float *llr_dev;
+    int64_t frames;
+    uint8_t *out_dev;
+    int64_t out_bytes;
+    int32_t *iters_dev;
+    int32_t K, max_iter, tap_iter, early_term;
+    int32_t *summary;
+};
+
+inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int32_t *launched)
+{
+    hipError_t e;
+    if ((e = hipMemsetAsync(r.summary, 0, 2 * sizeof(int32_t), s))) return e;
+    const int rounds = r.tap_iter ? (r.tap_iter < r.max_iter ? r.tap_iter : r.max_iter) : r.max_iter;
+    if (r.tap_iter && pl->dump_frames < r.frames) {
+        if (pl->dump_p) (void)hipFree(pl->dump_p);
+        if (pl->dump_r) (void)hipFree(pl->dump_r);
+        pl->dump_p = pl->dump_r = nullptr;
+        if ((e = hipMalloc((void **)&pl->dump_p, (size_t)r.frames * pl->N * sizeof(float)))) return e;
+        if ((e = hipMalloc((void **)&pl->dump_r, (size_t)r.frames * pl->E * sizeof(float)))) return e;
+        pl->dump_frames = r.frames;
+    }
+    FusedArgs a{r.llr_dev, r.out_dev, r.iters_dev, r.summary, r.tap_iter ? pl->dump_p : nullptr,
+                r.tap_iter ? pl->dump_r : nullptr, nullptr, pl->layer_ptr, pl->ent_bc, pl->ent_sh,
+                pl->layer_e0, r.frames, r.out_dev ? r.out_bytes : 0, pl->N, pl->E, r.K, pl->z, pl->layers,
+                r.max_iter, rounds, r.early_term};
+    const int mw = (pl->z + 63) / 64;
+    const unsigned grid = (unsigned)r.frames;
+    switch (mw) {
+    case 1: fused_layered_kernel<1><<<grid, 64, pl->lds_per_frame, s>>>(a); break;
+    case 2: fused_layered_kernel<2><<<grid, 128, pl->lds_per_frame, s>>>(a); break;
+    case 3: fused_layered_kernel<3><<<grid, 192, pl->lds_per_frame, s>>>(a); break;
+    case 4: fused_layered_kernel<4><<<grid, 256, pl->lds_per_frame, s>>>(a); break;
+    default: return hipErrorInvalidValue;
+    }
+    *launched = rounds;
+    return hipGetLastError();
+}
+
+}  // namespace ldpc

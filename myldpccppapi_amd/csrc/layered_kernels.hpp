@@ -363,12 +363,12 @@ inline hipError_t layered_run_v(LayeredPlan *pl, const LayeredRun &r, hipStream_
             if (r.span_end && (e = r.span_end(r.span_ctx, s))) return e;
         }
         /* syndrome of this round's bits, freeze (decodeCL.c:393-410) */
+        if (!r.early_term && it != rounds) continue;
         uint64_t *fw = r.failw + (size_t)it * slot;
         SyndromeArgs sa{r.row_ptr, r.edge_col, r.hard, fw, r.done, pl->M, pl->N, 0, 0};
         dim3 sgrid((pl->M + kBlock - 1) / kBlock, tiles);
         syndrome_kernel<V><<<sgrid, kBlock, 0, s>>>(sa);
-        StateArgs st{r.done, fw, r.iters, nullptr, r.frames, it, r.max_iter, r.early_term ? 1 : 0};
-        if (it == rounds) st.freeze = 1;   /* final bookkeeping: done == converged */
+        StateArgs st{r.done, fw, r.iters, nullptr, r.frames, it, r.max_iter, 1};
         state_kernel<V><<<tiles, 64, 0, s>>>(st);
     }
     *launched = rounds;

@@ -31,6 +31,7 @@
 #include "../../include/ldpc_hip.h"
 #include "flood_kernels.hpp"
 #include "layered_kernels.hpp"
+#include "fused_kernels.hpp"
 
 namespace {
 
@@ -177,7 +178,9 @@ struct ldpc_decoder {
     int max_check_unrolled = ldpc::kMaxUnrolledDegree;
     VarFn var_fn[ldpc::kMaxUnrolledDegree + 1] = {};
 
-    ldpc::LayeredPlan layered;          /* LDPC_ALGO_LAYERED */
+    ldpc::LayeredPlan layered;          /* LDPC_ALGO_LAYERED, streaming (one launch per layer) */
+    ldpc::FusedPlan fused;              /* LDPC_ALGO_LAYERED, short QC codes: whole decode in LDS */
+    bool use_fused = false;
 
     /* staging for the host-buffer entry point */
     hipStream_t stream = nullptr;
@@ -573,6 +576,13 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     HIP_TRY(d->summary.alloc(2));
 
     if (cfg->algo == LDPC_ALGO_LAYERED) {
+        /* short quasi-cyclic codes decode entirely in LDS, one launch (fused_kernels.hpp);
+         * LDPC_TUNE_FUSED=0 keeps the streaming kernels (same results, bit for bit) */
+        const char *fe = getenv("LDPC_TUNE_FUSED");
+        if (!(fe && atoi(fe) == 0) && (cfg->pack_mode == LDPC_PACK_BYTES || cfg->K % 8 == 0)) {
+            HIP_TRY(ldpc::fused_plan_create(&d->fused, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows));
+            d->use_fused = d->fused.eligible;
+        }
         int rc = ldpc::layered_plan_create(&d->layered, g->M, g->N, g->E, g->row_ptr, g->cols,
                                            cfg->layer_rows, d->T, d->V);
         if (rc == -1) return fail(LDPC_ERR_ARG, "layer_rows=%d must divide M=%d and rows of a layer "
@@ -621,6 +631,7 @@ int ldpc_decoder_destroy(ldpc_decoder *d)
     (void)hipSetDevice(d->cfg.device);
     (void)hipDeviceSynchronize();
     ldpc::layered_plan_destroy(&d->layered);
+    ldpc::fused_plan_destroy(&d->fused);
     delete d;
     return LDPC_OK;
 }
@@ -645,7 +656,14 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
     /* gaps between frames (K % 8 != 0, decodeCL.c:191-192 leaves them alone) read as 0 */
     if (out_dev) HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)std::min(out_bytes, need), s));
     int rc;
-    if (d->cfg.algo == LDPC_ALGO_LAYERED) {
+    if (d->cfg.algo == LDPC_ALGO_LAYERED && d->use_fused) {
+        ldpc::FusedRun run{llr_dev, frames, out_dev, std::min(out_bytes, need), iters_dev, d->cfg.K,
+                           d->cfg.max_iter, d->tap_iter, d->cfg.early_term, d->summary.p};
+        hipError_t e = span_begin(d, s, 2, 0, (int64_t)frames * (4 * d->N + d->cfg.K / 8));
+        if (e == hipSuccess) e = ldpc::fused_run(&d->fused, run, s, &d->last_iterations);
+        if (e == hipSuccess) e = span_end(d, s);
+        rc = (e == hipSuccess) ? LDPC_OK : fail(LDPC_ERR_HIP, "fused layered decode: %s", hipGetErrorString(e));
+    } else if (d->cfg.algo == LDPC_ALGO_LAYERED) {
         ldpc::LayeredRun run;
         run.span_begin = [](void *c, hipStream_t st, int kind, int deg, int64_t bytes) {
             return span_begin((ldpc_decoder *)c, st, kind, deg, bytes);
@@ -800,6 +818,19 @@ int ldpc_decoder_dump(ldpc_decoder *d, int32_t which, float *host_out, int64_t c
     const int64_t frames = d->last_frames;
     const int V = d->V, F = d->F;
     const int tiles = (int)((frames + F - 1) / F);
+    if (d->cfg.algo == LDPC_ALGO_LAYERED && d->use_fused) {
+        const float *src = which == 0 ? d->fused.dump_r : (which == 2 ? d->fused.dump_p : nullptr);
+        const int64_t per = which == 0 ? d->E : d->N;
+        if (which == 3) {           /* hard bits = P < 0 */
+            if (!d->fused.dump_p || count != frames * d->N) return fail(LDPC_ERR_ARG, "fused dump needs set_tap() and count = frames*N");
+            HIP_TRY(hipMemcpy(host_out, d->fused.dump_p, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < count; ++i) host_out[i] = host_out[i] < 0.0f ? 1.0f : 0.0f;
+            return LDPC_OK;
+        }
+        if (!src || count != frames * per) return fail(LDPC_ERR_ARG, "fused dump: set_tap() first; which in {0,2,3}");
+        HIP_TRY(hipMemcpy(host_out, src, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+        return LDPC_OK;
+    }
     if (d->cfg.algo == LDPC_ALGO_LAYERED) {
         hipError_t e = ldpc::layered_dump(&d->layered, which, host_out, count, frames, d->hard.p,
                                           d->h_cols.data());

@@ -98,6 +98,27 @@ def test_layered_bit_exact_vs_fused_reference_kernel(built, path, V):
     dec.close()
 
 
+def test_layered_streaming_and_fused_paths_agree(built, monkeypatch):
+    """Short QC codes take the fused LDS-resident kernel (one launch); LDPC_TUNE_FUSED=0 keeps
+    the one-launch-per-layer streaming kernels.  Both must give the oracle's bits."""
+    for rate, N, sigma, B in ((0, 576, 0.8, 70), (3, 1152, 0.55, 9), (0, 2304, 0.9, 6), (5, 960, 0.45, 130)):
+        g, og, K, M, z = _graph(rate, N)
+        y = channel.awgn_frames(N, 0, B, sigma, seed=13)
+        want = oracle.decode(og, y, "layered", layer_rows=z, tap_iter=3)
+        for fused in ("1", "0"):
+            monkeypatch.setenv("LDPC_TUNE_FUSED", fused)
+            dec = L.Decoder(g, K, max_batch=B, algo="layered", layer_rows=z)
+            out, iters = dec.decode(y)
+            assert np.array_equal(out, want["out"]) and np.array_equal(iters, want["iters"]), (rate, N, fused)
+            assert dec.stats()["frames_converged"] == int((want["iters"] < 40).sum()) or want["iters"].max() == 40
+            dec.set_tap(3)
+            dec.decode(y)
+            run = np.nonzero(want["iters"] >= 3)[0]
+            assert np.array_equal(dec.dump(0, B)[run], want["taps"]["r"][run]), fused
+            assert np.array_equal(dec.dump(2, B)[run], want["taps"]["post"][run]), fused
+            dec.close()
+
+
 @pytest.mark.parametrize("algo", ["ms", "sp", "layered"])
 def test_ragged_batches_and_chunking(built, algo):
     """frames not a multiple of the tile, more frames than max_batch (Coder::decode's
