@@ -70,7 +70,7 @@ def wimax_edges(rate, N):
 DVBS2_PROFILES = {
     (64800, 32400): [(8, 36), (3, 54)],     # rate 1/2:  E = 226 799, check degree 7 (row 0: 6)
     (64800, 58320): [(4, 18), (3, 144)],    # rate 9/10: E = 194 399, check degree 30
-    (16200, 7200): [(8, 5), (3, 15)],       # short frame "1/2" (4/9): q = 25
+    (12960, 6480): [(6, 6), (3, 12)],       # small check-regular instance for tests (not a standard size)
 }
 
 

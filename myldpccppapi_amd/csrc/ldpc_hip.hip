@@ -131,6 +131,14 @@ template <int V, typename T> struct CheckTableMS<V, T, ldpc::kMaxUnrolledDegree>
     static void fill(CheckFn *, CheckFn *) {}
 };
 
+using LinkFn = void (*)(const ldpc::CheckArgs, const ldpc::LinkArgs);
+template <int ALGO, int V, typename T, int D> struct LinkTable {
+    static void fill(LinkFn *t) { t[D] = ldpc::check_link_kernel<ALGO, D, V, T>; LinkTable<ALGO, V, T, D - 1>::fill(t); }
+};
+template <int ALGO, int V, typename T> struct LinkTable<ALGO, V, T, 1> {
+    static void fill(LinkFn *) {}
+};
+
 using InitFn = void (*)(const ldpc::InitArgs);
 template <int ALGO, typename T> InitFn pick_init(int V)
 {
@@ -142,6 +150,10 @@ struct RowClass {
     int degree = 0;
     int count = 0;
     DevBuf<int32_t> e0;
+    /* column-local fusion (check_link_kernel): per list row, the degree-2 column shared with
+     * the next list row when both fall in one wave's chunk of link_rpw rows */
+    DevBuf<int32_t> link_col, link_pos;
+    int linked = 0;          /* number of fused columns */
 };
 struct ColClass {
     int degree = 0;
@@ -176,6 +188,8 @@ struct ldpc_decoder {
     CheckFn check_fn[ldpc::kMaxUnrolledCheckDegreeMS + 1] = {};      /* narrow waves (1 value per lane) */
     CheckFn check_fn_wide[ldpc::kMaxUnrolledCheckDegreeMS + 1] = {}; /* V values per lane */
     int max_check_unrolled = ldpc::kMaxUnrolledDegree;
+    LinkFn link_fn[ldpc::kMaxUnrolledDegree + 1] = {};
+    int link_rpw = 16;                  /* rows per wave of the fused check kernel; 0 = fusion off */
     VarFn var_fn[ldpc::kMaxUnrolledDegree + 1] = {};
 
     ldpc::LayeredPlan layered;          /* LDPC_ALGO_LAYERED, streaming (one launch per layer) */
@@ -300,8 +314,21 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
     for (int it = 1; it <= rounds; ++it) {
         /* check_i: R_i = check(Q_{i-1}) */
         for (auto &rc : d->row_classes) {
-            HIP_TRY(span_begin(d, s, 0, rc.degree, 2 * msz * rc.degree * rc.count * frames));
+            /* algorithmic bytes: the fused columns' messages and channel values count as in the
+             * two-kernel formulation (16 E + 4 N per frame-iteration in total) */
+            HIP_TRY(span_begin(d, s, 0, rc.degree,
+                               (2 * msz * rc.degree * rc.count + msz * 5 * rc.linked) * frames));
             CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree};
+            if (rc.linked) {
+                LinkArgs lk{rc.link_col.p, rc.link_pos.p, d->chan.p, d->Q.p, d->hard.p, d->N,
+                            (it < max_iter) ? 1 : 0, d->tap_iter ? 1 : 0};
+                a.rows_per_wave = d->link_rpw;
+                const int waves = (rc.count + d->link_rpw - 1) / d->link_rpw;
+                dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
+                d->link_fn[rc.degree]<<<grid, kBlock, 0, s>>>(a, lk);
+                HIP_TRY(span_end(d, s));
+                continue;
+            }
             const int slotk = rc.degree <= d->max_check_unrolled ? rc.degree : 0;
             const bool narrow = slotk && (!d->tune_check_wide || rc.degree > kMaxUnrolledDegree);
             const int rpw = d->tune_rpw ? d->tune_rpw : (narrow ? 2 : 1);
@@ -378,15 +405,13 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
 
 int build_classes(ldpc_decoder *d, const ldpc_graph *g)
 {
-    std::map<int, std::vector<int32_t>> rows_by_deg, cols_by_deg;
+    std::map<int, std::vector<int32_t>> rows_by_deg, cols_by_deg, rowids_by_deg;
     for (int32_t m = 0; m < g->M; ++m) {
         const int deg = g->row_ptr[m + 1] - g->row_ptr[m];
-        if (deg > 0) rows_by_deg[deg].push_back(g->row_ptr[m]);
+        if (deg > 0) { rows_by_deg[deg].push_back(g->row_ptr[m]); rowids_by_deg[deg].push_back(m); }
     }
-    for (int32_t n = 0; n < g->N; ++n) {
-        const int deg = g->col_ptr[n + 1] - g->col_ptr[n];
-        cols_by_deg[deg].push_back(n);   /* degree 0: still needs its hard bit */
-    }
+    /* column-local fusion: degree-2 columns whose checks are consecutive list rows of one wave */
+    std::vector<char> fused_col((size_t)g->N, 0);
     d->row_classes.resize(rows_by_deg.size());
     size_t i = 0;
     for (auto &kv : rows_by_deg) {
@@ -394,6 +419,38 @@ int build_classes(ldpc_decoder *d, const ldpc_graph *g)
         rc.degree = kv.first;
         rc.count = (int)kv.second.size();
         HIP_TRY(rc.e0.upload(kv.second));
+        const std::vector<int32_t> &ids = rowids_by_deg[kv.first];
+        const int rpw = d->link_rpw;
+        if (rpw >= 2 && rc.degree >= 2 && rc.degree <= ldpc::kMaxUnrolledDegree) {
+            std::vector<int32_t> lcol((size_t)rc.count, -1), lpos((size_t)rc.count, 0);
+            for (int idx = 0; idx + 1 < rc.count; ++idx) {
+                if (idx % rpw == rpw - 1) continue;            /* next row belongs to another wave */
+                const int32_t m = ids[idx], m2 = ids[idx + 1];
+                for (int32_t p = g->row_ptr[m]; p < g->row_ptr[m + 1]; ++p) {
+                    const int32_t c = g->cols[p];
+                    if (g->col_ptr[c + 1] - g->col_ptr[c] != 2 || fused_col[c]) continue;
+                    const int32_t ea = g->col_edge[g->col_ptr[c]], eb = g->col_edge[g->col_ptr[c] + 1];
+                    if (ea != p || g->rows[eb] != m2) continue;   /* edges ascending: row m first */
+                    lcol[idx] = c;
+                    lpos[idx] = (p - g->row_ptr[m]) | ((eb - g->row_ptr[m2]) << 8);
+                    fused_col[c] = 1;
+                    ++rc.linked;
+                    break;
+                }
+            }
+            if (rc.linked * 4 >= rc.count) {                    /* worth a specialised kernel */
+                HIP_TRY(rc.link_col.upload(lcol));
+                HIP_TRY(rc.link_pos.upload(lpos));
+            } else {
+                for (int idx = 0; idx < rc.count; ++idx)
+                    if (lcol[idx] >= 0) fused_col[lcol[idx]] = 0;
+                rc.linked = 0;
+            }
+        }
+    }
+    for (int32_t n = 0; n < g->N; ++n) {
+        const int deg = g->col_ptr[n + 1] - g->col_ptr[n];
+        if (!fused_col[n]) cols_by_deg[deg].push_back(n);   /* degree 0: still needs its hard bit */
     }
     d->col_classes.resize(cols_by_deg.size());
     i = 0;
@@ -555,6 +612,7 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     if (const char *e = getenv("LDPC_TUNE_CPW")) d->tune_cpw = atoi(e);
     if (const char *e = getenv("LDPC_TUNE_SYN_XCD")) d->tune_syn_xcd = atoi(e);
     if (const char *e = getenv("LDPC_TUNE_CHECK_WIDE")) d->tune_check_wide = atoi(e);
+    if (const char *e = getenv("LDPC_TUNE_LINK_RPW")) d->link_rpw = atoi(e);
     d->V = pick_frames_per_lane(*cfg, g->max_row_deg, g->max_col_deg);
     d->F = 64 * d->V;
     d->T = (cfg->max_batch + d->F - 1) / d->F;
@@ -606,6 +664,9 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
         else if (d->V == 2) FloodTable<ALGO, 2, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn); \
         else FloodTable<ALGO, 4, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);            \
         d->init_fn = pick_init<ALGO, TYPE>(d->V);                                                      \
+        if (d->V == 1) LinkTable<ALGO, 1, TYPE, DM>::fill(d->link_fn);                                 \
+        else if (d->V == 2) LinkTable<ALGO, 2, TYPE, DM>::fill(d->link_fn);                            \
+        else LinkTable<ALGO, 4, TYPE, DM>::fill(d->link_fn);                                           \
     } while (0)
 #define LDPC_FILL_MS_HIGH(TYPE)                                                                         \
     do {                                                                                               \

@@ -213,6 +213,37 @@ def test_fp16_messages_follow_their_definition(built, V):
     assert e.value.code == 4
 
 
+@pytest.mark.parametrize("algo", ["sp", "ms"])
+def test_column_local_fusion_on_staircase_code(built, algo, monkeypatch):
+    """IRA (DVB-S2-profile) codes: the check kernel applies the variable-node update of the
+    staircase parity columns itself (check_link_kernel).  Small instance (N = 12960) checked
+    against the oracle: bytes, iteration counts and the messages of one round; fusion off
+    (LDPC_TUNE_LINK_RPW=0) must give the same."""
+    N2, K2 = 12960, 6480
+    rows, cols = codes.dvbs2_profile_edges(N2, K2)
+    g = L.Graph(rows, cols, N2 - K2, N2)
+    og = oracle.Graph(rows, cols, N2 - K2, N2, K2)
+    y = channel.awgn_frames(N2, 0, 70, 0.72 if algo == "ms" else 0.8, seed=14)
+    want = oracle.decode(og, y, algo, max_iter=25, tap_iter=2)
+    for rpw in ("8", "3", "0"):
+        monkeypatch.setenv("LDPC_TUNE_LINK_RPW", rpw)
+        for V in (1, 4):
+            dec = L.Decoder(g, K2, max_batch=70, algo=algo, max_iter=25, frames_per_lane=V)
+            out, iters = dec.decode(y)
+            assert np.array_equal(out, want["out"]) and np.array_equal(iters, want["iters"]), (rpw, V)
+            dec.set_tap(2)
+            dec.decode(y)
+            run_q = np.nonzero(want["iters"] > 2)[0]
+            Q = dec.dump(1, 70)
+            if algo == "ms":
+                assert np.array_equal(Q[run_q], want["taps"]["q"][run_q], equal_nan=True), (rpw, V)
+                assert np.array_equal(dec.dump(0, 70)[run_q], want["taps"]["r"][run_q]), (rpw, V)
+            else:
+                dq = want["taps"]["q0"] - want["taps"]["q1"]
+                assert np.array_equal(Q[run_q], dq[run_q], equal_nan=True), (rpw, V)
+            dec.close()
+
+
 def test_generic_degree_kernels(built):
     """Degrees above the unrolled range take the generic kernels: the rate-5/6 seed has
     row weight 20 (flooding check / layered rows)."""
