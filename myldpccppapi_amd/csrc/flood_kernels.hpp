@@ -493,24 +493,41 @@ __global__ __launch_bounds__(kBlock) void check_link_kernel(const CheckArgs a, c
 #pragma unroll
     for (int v = 0; v < V; ++v) pend_r[v] = 0.0f;
 
+    /* software pipeline: row r+1's messages are requested before row r is worked on */
+    float x[D][V];
+    if (r_begin < r_end) {
+        const int e0 = a.cls_e0[r_begin];
+#pragma unroll
+        for (int k = 0; k < D; ++k) vload<V>(x[k], Qt + (size_t)(e0 + k) * F);
+    }
     for (int r = r_begin; r < r_end; ++r) {
         const int e0 = a.cls_e0[r];
         const int next_col = (r + 1 < r_end) ? g.link_col[r] : -1;
         const int pos = g.link_pos[r];
         const int ka = next_col >= 0 ? (pos & 255) : -1;      /* this row's edge into next_col */
         const int kb = pend_col >= 0 ? pend_kb : -1;          /* this row's edge into pend_col */
-        float x[D][V], out[D][V];
+        /* everything the pending column needs besides this row's result: request it now */
+        float ch[V];
+        uint64_t old_w[V];
+        if (pend_col >= 0) {
+            vload<V>(ch, chan_t + (size_t)pend_col * F);
 #pragma unroll
-        for (int k = 0; k < D; ++k) vload<V>(x[k], Qt + (size_t)(e0 + k) * F);
+            for (int v = 0; v < V; ++v) old_w[v] = hard_t[(size_t)pend_col * V + v];
+        }
+        float out[D][V];
         if (ALGO == kAlgoSP) check_sp<D, V>(x, out); else check_ms<D, V>(x, out);
+        if (r + 1 < r_end) {
+            const int e1 = a.cls_e0[r + 1];
+#pragma unroll
+            for (int k = 0; k < D; ++k) vload<V>(x[k], Qt + (size_t)(e1 + k) * F);
+        }
 #pragma unroll
         for (int k = 0; k < D; ++k)
             if ((k != ka && k != kb) || g.store_all) vstore<V>(Rt + (size_t)(e0 + k) * F, out[k]);
 
         if (pend_col >= 0) {
             /* variable node of pend_col: edges (previous row, ka') then (this row, kb), ascending */
-            float ch[V], rr[2][V], q[2][V];
-            vload<V>(ch, chan_t + (size_t)pend_col * F);
+            float rr[2][V], q[2][V];
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 rr[0][v] = pend_r[v];
@@ -519,9 +536,7 @@ __global__ __launch_bounds__(kBlock) void check_link_kernel(const CheckArgs a, c
                 for (int k = 1; k < D; ++k) t = (k == kb) ? out[k][v] : t;
                 rr[1][v] = t;
             }
-            uint64_t old_w[V], new_w[V];
-#pragma unroll
-            for (int v = 0; v < V; ++v) old_w[v] = hard_t[(size_t)pend_col * V + v];
+            uint64_t new_w[V];
             if (ALGO == kAlgoSP) {
                 float f0[V], f1[V];
                 var_sp<2, V>(ch, rr, q, f0, f1);

@@ -30,17 +30,23 @@ def short(name):
 
 def display(name):
     """check_kernel<0, 7, 4> -> check_kernel<sp,7,4> (the names bench.py prints)"""
-    m = re.match(r"(check_kernel|var_kernel)<(\d), (\d+), (\d)(?:, \d)?, (float|_Float16)>", name)
+    m = re.match(r"(check_kernel|check_link_kernel|var_kernel)<(\d), (\d+), (\d)(?:, \d)?, (float|_Float16)>", name)
     if m:
         algo = ("sp", "ms")[int(m.group(2))] + ("16" if m.group(5) != "float" else "")
-        return "%s<%s,%s,%s>" % (m.group(1), algo, m.group(3), m.group(4))
+        # bench.py names kernels by phase: the linked check kernel is the check phase of its degree
+        return "%s<%s,%s,%s>" % ("check_kernel" if m.group(1) != "var_kernel" else "var_kernel", algo, m.group(3), m.group(4))
     m = re.match(r"layer_kernel<(\d+), (\d)>", name)
     if m:
         return "layer_kernel<layered,%s,%s>" % (m.group(1), m.group(2))
     return name
 
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+def newest(pattern):
+    files = glob.glob(pattern)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
+stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 rows = []
 if stats:
     for r in csv.DictReader(open(stats[0])):
@@ -54,7 +60,7 @@ if stats:
 
 pmc = {}
 for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-    files = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+    files = newest(os.path.join(src, sub, "*", "*_counter_collection.csv"))
     if not files:
         continue
     acc = {}
@@ -76,7 +82,7 @@ for k, v in pmc.items():
         # wave-instruction): every Q byte is read exactly once (no reuse is possible), the
         # algorithmic read volume is 3.716 GB per launch and the raw counter shows 1.859 GB,
         # i.e. exactly 1/2 as well.
-        wide = bool(re.search(r"^(var_kernel|layer_kernel|check_kernel)<", k))
+        wide = bool(re.search(r"^(var_kernel|layer_kernel|check_kernel|check_link_kernel)<", k))
         fetch = v["FETCH_SIZE_KiB_per_launch"] * 1024 * (2 if wide else 1)
         write = v["WRITE_SIZE_KiB_per_launch"] * 1024
         v["fetch_correction"] = 2 if wide else 1
