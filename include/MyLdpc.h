@@ -21,7 +21,8 @@
  *     decodeCPU, MyLdpc.cpp:684-784, including its bit-offset packing); there is
  *     no CPU decode path in this library.
  *   - DecodeTDMP and DecodeTDMPCL both run the layered schedule with the
- *     semantics of the fused kernel (decodeCL.c:307-426); DecodeMSCL is not built.
+ *     semantics of the fused kernel (decodeCL.c:307-426); DecodeMSCL runs the fused
+ *     flooding kernel's arithmetic (decodeCL.c:432-567, 120 iterations as there).
  *   - `times` (MyLdpc.cpp:24) and the SP channel scale 8 (decodeCL.c:9) stay the
  *     defaults and can be changed with setMaxIterations()/setLlrScale().
  */

@@ -51,11 +51,16 @@ enum ldpc_status {
 /* decodeType of the reference (MyLdpc.h:37-39) maps as:
  *   DecodeSP                 -> LDPC_ALGO_SP       (decodeCL.c:3-108)
  *   DecodeMS, DecodeCPU      -> LDPC_ALGO_MS       (decodeCL.c:113-186, MyLdpc.cpp:684-784)
- *   DecodeTDMP, DecodeTDMPCL -> LDPC_ALGO_LAYERED  (semantics of decodeCL.c:307-426) */
+ *   DecodeTDMP, DecodeTDMPCL -> LDPC_ALGO_LAYERED  (semantics of decodeCL.c:307-426)
+ *   DecodeMSCL               -> LDPC_ALGO_MS_FUSED (decodeCL.c:432-567) */
 enum ldpc_algo {
     LDPC_ALGO_SP = 0,      /* flooding sum-product, probability domain, fp32     */
     LDPC_ALGO_MS = 1,      /* flooding min-sum, fp32                             */
-    LDPC_ALGO_LAYERED = 2  /* layered (TDMP) min-sum                             */
+    LDPC_ALGO_LAYERED = 2, /* layered (TDMP) min-sum                             */
+    LDPC_ALGO_MS_FUSED = 3 /* flooding min-sum with the arithmetic of the fused kernel
+                              decodeOnceMS (DecodeMSCL, decodeCL.c:432-567): short
+                              quasi-cyclic codes only, whole decode in LDS; the reference
+                              hard-codes max_iter = 120 there                            */
 };
 
 enum ldpc_msg_dtype { LDPC_MSG_F32 = 0, LDPC_MSG_F16 = 1 };
@@ -79,7 +84,7 @@ typedef struct ldpc_decoder_config {
     int32_t early_term;     /* 1: frames freeze when their syndrome is clean (reference
                                behaviour, decodeCL.c:27,48-49); 0: always run max_iter      */
     int32_t device;         /* HIP device ordinal                                          */
-    int32_t layer_rows;     /* LDPC_ALGO_LAYERED: rows per layer (z)                       */
+    int32_t layer_rows;     /* LDPC_ALGO_LAYERED / MS_FUSED: rows per layer = circulant size z */
     int32_t pack_mode;      /* enum ldpc_pack_mode                                         */
     int32_t frames_per_lane;/* tuning: 0 = auto, else 1, 2 or 4 (tile = 64*frames_per_lane) */
     int32_t poll_interval;  /* early_term: host checks "all frames done" every this many

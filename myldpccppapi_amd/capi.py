@@ -11,10 +11,10 @@ import numpy as np
 from . import _lib
 from ._lib import DecoderConfig, DecodeStats, LdpcError  # noqa: F401
 
-ALGO_SP, ALGO_MS, ALGO_LAYERED = 0, 1, 2
+ALGO_SP, ALGO_MS, ALGO_LAYERED, ALGO_MS_FUSED = 0, 1, 2, 3
 MSG_F32, MSG_F16 = 0, 1
 PACK_BYTES, PACK_BITS = 0, 1
-ALGOS = {"sp": ALGO_SP, "ms": ALGO_MS, "layered": ALGO_LAYERED}
+ALGOS = {"sp": ALGO_SP, "ms": ALGO_MS, "layered": ALGO_LAYERED, "ms_fused": ALGO_MS_FUSED}
 
 
 def device_count():

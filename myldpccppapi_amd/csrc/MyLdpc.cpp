@@ -223,8 +223,6 @@ int Coder::forDecoder(int batchSize)
 int Coder::addDecodeType(enum decodeType deType)
 {
     if (!isDecoder) return fail(LDPC_ERR_STATE, "addDecodeType: call forDecoder() first");
-    if (deType == DecodeMSCL)
-        return fail(LDPC_ERR_UNSUPPORTED, "DecodeMSCL (fused short-code min-sum, decodeCL.c:432-567) is not built");
     if (decoders.count((int)deType)) return LDPC_SUCCESS;
     if (deType == DecodeCPU) return LDPC_SUCCESS;   /* made on first use: needs the stream length (:438-439 is a no-op too) */
     ldpc_decoder_config cfg;
@@ -238,7 +236,9 @@ int Coder::addDecodeType(enum decodeType deType)
     cfg.poll_interval = 4;
     cfg.pack_mode = LDPC_PACK_BYTES;
     cfg.layer_rows = z;
-    cfg.algo = (deType == DecodeSP) ? LDPC_ALGO_SP : (deType == DecodeMS) ? LDPC_ALGO_MS : LDPC_ALGO_LAYERED;
+    cfg.algo = (deType == DecodeSP) ? LDPC_ALGO_SP : (deType == DecodeMS) ? LDPC_ALGO_MS
+               : (deType == DecodeMSCL) ? LDPC_ALGO_MS_FUSED : LDPC_ALGO_LAYERED;
+    if (deType == DecodeMSCL) cfg.max_iter = 120;      /* hard-coded in the reference kernel, decodeCL.c:479 */
     ldpc_decoder *d = nullptr;
     int rc = ldpc_decoder_create(graph, &cfg, &d);
     if (rc) return fail(rc, ldpc_last_error());

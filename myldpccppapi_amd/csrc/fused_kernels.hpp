@@ -47,6 +47,11 @@ struct FusedArgs {
     const int32_t *__restrict__ ent_bc;   /* block column of entry */
     const int32_t *__restrict__ ent_sh;   /* circulant shift of entry */
     const int32_t *__restrict__ layer_e0; /* [layers] edge id of the layer's first edge */
+    /* column view for the flooding variant: block column bc is met by entries
+     * bcol_ptr[bc]..bcol_ptr[bc+1], ascending layer = ascending row */
+    const int32_t *__restrict__ bcol_ptr; /* [N/z + 1] */
+    const int32_t *__restrict__ bcol_e0;  /* LDS slot of (layer, k): layer_e0[l] + k*z */
+    const int32_t *__restrict__ bcol_sh;  /* shift of that block */
     int64_t frames, out_bytes;
     int32_t N, E, K, z, layers, max_iter, rounds, early_term;
 };
@@ -168,12 +173,124 @@ __global__ __launch_bounds__(64 * MW) void fused_layered_kernel(const FusedArgs 
     }
 }
 
+/* Flooding counterpart: the reference's fused kernel decodeOnceMS (decodeCL.c:432-567,
+ * DecodeMSCL).  Every iteration: all rows from the same posteriors (check node with the
+ * product sign and the 1000/1001 two-minimum rule, :482-512), then every posterior rebuilt
+ * as y + sum of its column's R in ascending row order (:515-531), bits = P < 0, syndrome.
+ * Same LDS layout and lane mapping as fused_layered_kernel; y is re-read from global memory
+ * (L2) instead of being kept in LDS. */
+template <int MW>
+__global__ __launch_bounds__(64 * MW) void fused_flood_kernel(const FusedArgs a)
+{
+    extern __shared__ float lds[];
+    const int tid = (int)threadIdx.x;
+    const int64_t frame = (int64_t)blockIdx.x;
+    float *P = lds;
+    float *R = P + a.N;
+    constexpr int LANES = 64 * MW;
+    const int z = a.z;
+    const int r = tid;
+    auto sync = [&]() {
+        if (MW == 1) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __syncthreads();
+        }
+    };
+    const float *y = a.llr + (size_t)frame * a.N;
+    for (int n = tid; n < a.N; n += LANES) P[n] = y[n];       /* :469-471 */
+    for (int e = tid; e < a.E; e += LANES) R[e] = 0.0f;       /* :474-476 */
+    sync();
+    int time = 0;
+    bool clean = false;
+    while (true) {
+        if (r < z) {
+            for (int l = 0; l < a.layers; ++l) {               /* rows never touch P here */
+                const int p0 = a.layer_ptr[l], d = a.layer_ptr[l + 1] - p0;
+                float *Rl = R + a.layer_e0[l];
+                float prod = 1.0f, b = 1000.0f, c = 1001.0f;
+                int bind = -1;
+                for (int k = 0; k < d; ++k) {                  /* :486-501 */
+                    int t = r + a.ent_sh[p0 + k];
+                    t = t >= z ? t - z : t;
+                    const float q = P[a.ent_bc[p0 + k] * z + t] - Rl[k * z + r];
+                    Rl[k * z + r] = cl_sign(q);
+                    prod *= q;
+                    const float mag = __builtin_fabsf(q);
+                    if (mag <= b) { c = b; b = mag; bind = k; }
+                    else if (mag > b && mag <= c) { c = mag; }
+                }
+                const float sa = cl_sign(prod);                /* :502 */
+                const float ab = sa * b, ac = sa * c;
+                for (int k = 0; k < d; ++k)                    /* :504-513 */
+                    Rl[k * z + r] = Rl[k * z + r] * ((k == bind) ? ac : ab);
+            }
+        }
+        sync();                                                /* :514 */
+        for (int n = tid; n < a.N; n += LANES) {               /* :515-531 */
+            const int bc = n / z, t = n - bc * z;
+            float tmp = y[n];
+            for (int j = a.bcol_ptr[bc]; j < a.bcol_ptr[bc + 1]; ++j) {
+                int rr = t - a.bcol_sh[j];
+                rr = rr < 0 ? rr + z : rr;
+                tmp += R[a.bcol_e0[j] + rr];
+            }
+            P[n] = tmp;
+        }
+        sync();                                                /* :532 */
+        int bad = 0;
+        if (r < z) {
+            for (int l = 0; l < a.layers; ++l) {
+                const int p0 = a.layer_ptr[l], d = a.layer_ptr[l + 1] - p0;
+                int par = 0;
+                for (int k = 0; k < d; ++k) {
+                    int t = r + a.ent_sh[p0 + k];
+                    t = t >= z ? t - z : t;
+                    par ^= (P[a.ent_bc[p0 + k] * z + t] < 0.0f) ? 1 : 0;
+                }
+                bad |= par;
+            }
+        }
+        const int any_bad = (MW == 1) ? (__ballot(bad != 0) != 0ull) : __syncthreads_or(bad);
+        ++time;
+        clean = !any_bad;
+        if ((clean && a.early_term) || time == a.rounds) break; /* :555-559 */
+    }
+    sync();
+    const int64_t base = frame * (int64_t)a.K / 8;
+    for (int j = tid; j < a.K / 8; j += LANES) {                /* :561-569 */
+        unsigned byte = 0;
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) byte |= (P[j * 8 + bit] < 0.0f ? 1u : 0u) << bit;
+        if (base + j < a.out_bytes) a.out[base + j] = (uint8_t)byte;
+    }
+    if (a.dump_p)
+        for (int n = tid; n < a.N; n += LANES) a.dump_p[(size_t)frame * a.N + n] = P[n];
+    if (a.dump_r) {
+        for (int l = 0; l < a.layers; ++l) {
+            const int d = a.layer_ptr[l + 1] - a.layer_ptr[l], e0 = a.layer_e0[l];
+            for (int i = tid; i < d * z; i += LANES) {
+                const int rr = i / d, k = i % d;
+                a.dump_r[(size_t)frame * a.E + e0 + i] = R[e0 + k * z + rr];
+            }
+        }
+    }
+    if (tid == 0) {
+        const int it = clean ? time : a.max_iter;
+        if (a.iters) a.iters[frame] = it;
+        atomicMax(&a.summary[0], it);
+        if (clean) atomicAdd(&a.summary[1], 1);
+    }
+}
+
 /* ---------------------------------------------------------------- host side */
 
 struct FusedPlan {
     bool eligible = false;
     int32_t z = 0, layers = 0, N = 0, E = 0, M = 0;
     int32_t *layer_ptr = nullptr, *ent_bc = nullptr, *ent_sh = nullptr, *layer_e0 = nullptr; /* device */
+    int32_t *bcol_ptr = nullptr, *bcol_e0 = nullptr, *bcol_sh = nullptr;
     float *dump_p = nullptr, *dump_r = nullptr;
     uint8_t *conv = nullptr;
     int64_t dump_frames = 0;
@@ -183,6 +300,7 @@ struct FusedPlan {
 inline void fused_plan_destroy(FusedPlan *pl)
 {
     for (void *p : {(void *)pl->layer_ptr, (void *)pl->ent_bc, (void *)pl->ent_sh, (void *)pl->layer_e0,
+                    (void *)pl->bcol_ptr, (void *)pl->bcol_e0, (void *)pl->bcol_sh,
                     (void *)pl->dump_p, (void *)pl->dump_r, (void *)pl->conv})
         if (p) (void)hipFree(p);
     *pl = FusedPlan();
@@ -245,6 +363,21 @@ inline hipError_t fused_plan_create(FusedPlan *pl, int32_t M, int32_t N, int64_t
     if ((e = up(&pl->layer_ptr, lp)) || (e = up(&pl->ent_bc, bc)) || (e = up(&pl->ent_sh, sh)) ||
         (e = up(&pl->layer_e0, e0)))
         return e;
+    /* column view: entries of every block column in ascending layer order */
+    const int nb = N / z, layers = M / z;
+    std::vector<int32_t> cp((size_t)nb + 1, 0), ce0, csh;
+    for (int l = 0; l < layers; ++l)
+        for (int j = lp[l]; j < lp[l + 1]; ++j) ++cp[bc[j] + 1];
+    for (int b = 0; b < nb; ++b) cp[b + 1] += cp[b];
+    ce0.assign(cp[nb], 0); csh.assign(cp[nb], 0);
+    std::vector<int32_t> fill(cp.begin(), cp.end() - 1);
+    for (int l = 0; l < layers; ++l)
+        for (int j = lp[l]; j < lp[l + 1]; ++j) {
+            const int slot = fill[bc[j]]++;
+            ce0[slot] = e0[l] + (j - lp[l]) * z;
+            csh[slot] = sh[j];
+        }
+    if ((e = up(&pl->bcol_ptr, cp)) || (e = up(&pl->bcol_e0, ce0)) || (e = up(&pl->bcol_sh, csh))) return e;
     pl->eligible = true;
     return hipSuccess;
 }
@@ -257,6 +390,7 @@ struct FusedRun {
     int32_t *iters_dev;
     int32_t K, max_iter, tap_iter, early_term;
     int32_t *summary;
+    int32_t flooding;   /* 0: layered (decodeOnceTDMP), 1: flooding (decodeOnceMS) */
 };
 
 inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int32_t *launched)
@@ -274,16 +408,26 @@ inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int
     }
     FusedArgs a{r.llr_dev, r.out_dev, r.iters_dev, r.summary, r.tap_iter ? pl->dump_p : nullptr,
                 r.tap_iter ? pl->dump_r : nullptr, nullptr, pl->layer_ptr, pl->ent_bc, pl->ent_sh,
-                pl->layer_e0, r.frames, r.out_dev ? r.out_bytes : 0, pl->N, pl->E, r.K, pl->z, pl->layers,
+                pl->layer_e0, pl->bcol_ptr, pl->bcol_e0, pl->bcol_sh, r.frames, r.out_dev ? r.out_bytes : 0, pl->N, pl->E, r.K, pl->z, pl->layers,
                 r.max_iter, rounds, r.early_term};
     const int mw = (pl->z + 63) / 64;
     const unsigned grid = (unsigned)r.frames;
-    switch (mw) {
-    case 1: fused_layered_kernel<1><<<grid, 64, pl->lds_per_frame, s>>>(a); break;
-    case 2: fused_layered_kernel<2><<<grid, 128, pl->lds_per_frame, s>>>(a); break;
-    case 3: fused_layered_kernel<3><<<grid, 192, pl->lds_per_frame, s>>>(a); break;
-    case 4: fused_layered_kernel<4><<<grid, 256, pl->lds_per_frame, s>>>(a); break;
-    default: return hipErrorInvalidValue;
+    if (r.flooding) {
+        switch (mw) {
+        case 1: fused_flood_kernel<1><<<grid, 64, pl->lds_per_frame, s>>>(a); break;
+        case 2: fused_flood_kernel<2><<<grid, 128, pl->lds_per_frame, s>>>(a); break;
+        case 3: fused_flood_kernel<3><<<grid, 192, pl->lds_per_frame, s>>>(a); break;
+        case 4: fused_flood_kernel<4><<<grid, 256, pl->lds_per_frame, s>>>(a); break;
+        default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (mw) {
+        case 1: fused_layered_kernel<1><<<grid, 64, pl->lds_per_frame, s>>>(a); break;
+        case 2: fused_layered_kernel<2><<<grid, 128, pl->lds_per_frame, s>>>(a); break;
+        case 3: fused_layered_kernel<3><<<grid, 192, pl->lds_per_frame, s>>>(a); break;
+        case 4: fused_layered_kernel<4><<<grid, 256, pl->lds_per_frame, s>>>(a); break;
+        default: return hipErrorInvalidValue;
+        }
     }
     *launched = rounds;
     return hipGetLastError();

@@ -581,7 +581,8 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     if (cfg->K <= 0 || cfg->K > g->N) return fail(LDPC_ERR_ARG, "K=%d out of range", cfg->K);
     if (cfg->max_batch <= 0) return fail(LDPC_ERR_ARG, "max_batch must be positive");
     if (cfg->max_iter <= 0 || cfg->max_iter > 100000) return fail(LDPC_ERR_ARG, "max_iter out of range");
-    if (cfg->algo != LDPC_ALGO_SP && cfg->algo != LDPC_ALGO_MS && cfg->algo != LDPC_ALGO_LAYERED)
+    if (cfg->algo != LDPC_ALGO_SP && cfg->algo != LDPC_ALGO_MS && cfg->algo != LDPC_ALGO_LAYERED &&
+        cfg->algo != LDPC_ALGO_MS_FUSED)
         return fail(LDPC_ERR_ARG, "unknown algo %d", cfg->algo);
     if (cfg->pack_mode != LDPC_PACK_BYTES && cfg->pack_mode != LDPC_PACK_BITS)
         return fail(LDPC_ERR_ARG, "unknown pack_mode %d", cfg->pack_mode);
@@ -633,7 +634,15 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     HIP_TRY(d->active.alloc(1));
     HIP_TRY(d->summary.alloc(2));
 
-    if (cfg->algo == LDPC_ALGO_LAYERED) {
+    if (cfg->algo == LDPC_ALGO_MS_FUSED) {
+        if (cfg->pack_mode != LDPC_PACK_BYTES && cfg->K % 8)
+            return fail(LDPC_ERR_UNSUPPORTED, "MS_FUSED packs whole bytes per frame only");
+        HIP_TRY(ldpc::fused_plan_create(&d->fused, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows));
+        if (!d->fused.eligible)
+            return fail(LDPC_ERR_UNSUPPORTED, "MS_FUSED needs a quasi-cyclic H with circulant size "
+                        "layer_rows <= 256 and (N+E)*4 B <= %zu B of LDS per frame", ldpc::kFusedMaxLdsPerFrame);
+        d->use_fused = true;
+    } else if (cfg->algo == LDPC_ALGO_LAYERED) {
         /* short quasi-cyclic codes decode entirely in LDS, one launch (fused_kernels.hpp);
          * LDPC_TUNE_FUSED=0 keeps the streaming kernels (same results, bit for bit) */
         const char *fe = getenv("LDPC_TUNE_FUSED");
@@ -717,13 +726,14 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
     /* gaps between frames (K % 8 != 0, decodeCL.c:191-192 leaves them alone) read as 0 */
     if (out_dev) HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)std::min(out_bytes, need), s));
     int rc;
-    if (d->cfg.algo == LDPC_ALGO_LAYERED && d->use_fused) {
+    if (d->use_fused) {
         ldpc::FusedRun run{llr_dev, frames, out_dev, std::min(out_bytes, need), iters_dev, d->cfg.K,
-                           d->cfg.max_iter, d->tap_iter, d->cfg.early_term, d->summary.p};
+                           d->cfg.max_iter, d->tap_iter, d->cfg.early_term, d->summary.p,
+                           d->cfg.algo == LDPC_ALGO_MS_FUSED ? 1 : 0};
         hipError_t e = span_begin(d, s, 2, 0, (int64_t)frames * (4 * d->N + d->cfg.K / 8));
         if (e == hipSuccess) e = ldpc::fused_run(&d->fused, run, s, &d->last_iterations);
         if (e == hipSuccess) e = span_end(d, s);
-        rc = (e == hipSuccess) ? LDPC_OK : fail(LDPC_ERR_HIP, "fused layered decode: %s", hipGetErrorString(e));
+        rc = (e == hipSuccess) ? LDPC_OK : fail(LDPC_ERR_HIP, "fused decode: %s", hipGetErrorString(e));
     } else if (d->cfg.algo == LDPC_ALGO_LAYERED) {
         ldpc::LayeredRun run;
         run.span_begin = [](void *c, hipStream_t st, int kind, int deg, int64_t bytes) {
@@ -835,8 +845,8 @@ int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t ca
     HIP_TRY(hipSetDevice(d->cfg.device));
     HIP_TRY(hipEventSynchronize(d->ev_end));
     static const char *phase_name[] = {"check_kernel", "var_kernel", "layer_kernel", "other"};
-    static const char *algo_name_f32[] = {"sp", "ms", "layered"};
-    static const char *algo_name_f16[] = {"sp16", "ms16", "layered16"};
+    static const char *algo_name_f32[] = {"sp", "ms", "layered", "ms_fused"};
+    static const char *algo_name_f16[] = {"sp16", "ms16", "layered16", "ms_fused16"};
     const char **algo_name = d->msg_size == 2 ? algo_name_f16 : algo_name_f32;
     for (size_t i = 0; i < d->spans_used; ++i) {
         const TimedSpan &sp = d->spans[i];
@@ -879,7 +889,7 @@ int ldpc_decoder_dump(ldpc_decoder *d, int32_t which, float *host_out, int64_t c
     const int64_t frames = d->last_frames;
     const int V = d->V, F = d->F;
     const int tiles = (int)((frames + F - 1) / F);
-    if (d->cfg.algo == LDPC_ALGO_LAYERED && d->use_fused) {
+    if (d->use_fused) {
         const float *src = which == 0 ? d->fused.dump_r : (which == 2 ? d->fused.dump_p : nullptr);
         const int64_t per = which == 0 ? d->E : d->N;
         if (which == 3) {           /* hard bits = P < 0 */

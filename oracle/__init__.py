@@ -59,6 +59,8 @@ def lib():
         L.oracle_decode_layered.restype = ctypes.c_int
         L.oracle_decode_layered.argtypes = common + [ctypes.c_int32, _f32p, ctypes.c_int64,
                                                      ctypes.c_int] + tail + [_u8p]
+        L.oracle_decode_ms_fused.restype = ctypes.c_int
+        L.oracle_decode_ms_fused.argtypes = common + [_f32p, ctypes.c_int64, ctypes.c_int] + tail + [_u8p]
         L.oracle_code_size.restype = ctypes.c_int64
         L.oracle_code_size.argtypes = [ctypes.c_int64, ctypes.c_int32]
         L.oracle_test_channel.restype = None
@@ -113,6 +115,7 @@ def out_len(frames, K, pack_mode=0):
 def decode(g, y, algo, max_iter=40, llr_scale=8.0, pack_mode=0, layer_rows=0, tap_iter=0, msg_f16=False):
     """Run one oracle decoder.  algo in {"ms", "sp", "layered"}.
 
+    "ms_fused" = the arithmetic of the reference's fused flooding kernel (DecodeMSCL).
     Returns dict(out=bytes array, iters=int32[frames], hard=uint8[frames,N],
     taps=dict of float arrays when tap_iter > 0)."""
     L = lib()
@@ -126,7 +129,7 @@ def decode(g, y, algo, max_iter=40, llr_scale=8.0, pack_mode=0, layer_rows=0, ta
     if tap_iter:
         ctaps = _Taps()
         ctaps.iter = tap_iter
-        names = ("r", "q", "post") if algo != "sp" else ("r0", "r1", "q0", "q1")
+        names = ("r0", "r1", "q0", "q1") if algo == "sp" else (("r", "post") if algo in ("layered", "ms_fused") else ("r", "q", "post"))
         for nm in names:
             n = g.N if nm == "post" else g.E
             taps[nm] = np.full((frames, n), np.nan, np.float32)
@@ -142,12 +145,16 @@ def decode(g, y, algo, max_iter=40, llr_scale=8.0, pack_mode=0, layer_rows=0, ta
         undef = np.zeros(frames, np.uint8)
         rc = L.oracle_decode_layered(ctypes.byref(g._c), layer_rows, _p(y, _f32p), frames,
                                      max_iter, *tail, _p(undef, _u8p))
+    elif algo == "ms_fused":
+        undef = np.zeros(frames, np.uint8)
+        rc = L.oracle_decode_ms_fused(ctypes.byref(g._c), _p(y, _f32p), frames, max_iter, *tail,
+                                      _p(undef, _u8p))
     else:
         raise ValueError(algo)
     if rc:
         raise RuntimeError("oracle decode failed rc=%d" % rc)
     res = dict(out=out, iters=iters, hard=hard, taps=taps)
-    if algo == "layered":
+    if algo in ("layered", "ms_fused"):
         res["undefined"] = undef
     return res
 

@@ -407,6 +407,72 @@ int oracle_decode_layered(const oracle_graph *g, int32_t layer_rows, const float
     return 0;
 }
 
+/* --------------------------------------------- fused flooding min-sum (MSCL) */
+
+/* The arithmetic of the fused flooding kernel decodeOnceMS, decodeCL.c:432-567
+ * (launched by Coder::decodeOnceMSCL, MyLdpc.cpp:870-888; `times` is hard-coded to 120
+ * there, :479), on a general edge list.  It differs from the MS kernel chain in the
+ * check node -- sign through the fp32 PRODUCT of the inputs (a zero or underflowed
+ * product zeroes the row), two smallest magnitudes with start values 1000 / 1001 and
+ * `<=` ties (:482-512) -- and in the hard decision, bit = P < 0 (:541).  Posteriors
+ * are rebuilt every iteration as y + sum of R in ascending row order (:515-531).
+ * undefined_frames as in oracle_decode_layered (same uninitialised `bInd`, :485). */
+int oracle_decode_ms_fused(const oracle_graph *g, const float *y, int64_t frames, int max_iter,
+                           int pack_mode, uint8_t *out, int64_t out_bytes, int32_t *iters,
+                           uint8_t *hard_out, const oracle_taps *taps, uint8_t *undefined_frames)
+{
+    const int64_t E = g->E;
+    const int32_t N = g->N, M = g->M;
+    float *lP = (float *)malloc(sizeof(float) * (size_t)N);
+    float *lR = (float *)malloc(sizeof(float) * (size_t)E);
+    uint8_t *src = (uint8_t *)calloc((size_t)N, 1);
+    if (!lP || !lR || !src) return -2;
+    for (int64_t f = 0; f < frames; ++f) {
+        const float *yf = y + f * N;
+        int time = 0;
+        if (undefined_frames) undefined_frames[f] = 0;
+        memcpy(lP, yf, sizeof(float) * (size_t)N);          /* :469-471 */
+        for (int64_t e = 0; e < E; ++e) lR[e] = 0;          /* :474-476 */
+        while (1) {
+            for (int32_t row = 0; row < M; ++row) {         /* :482-512, all rows from the same lP */
+                const int32_t lo = g->row_ptr[row], hi = g->row_ptr[row + 1];
+                float a = 1, b = 1000, c = 1001;
+                int32_t bInd = -1;
+                for (int32_t p = lo; p < hi; ++p) {
+                    float tmp = lP[g->cols[p]] - lR[p];
+                    lR[p] = cl_sign(tmp);
+                    a *= tmp;
+                    tmp = fabsf(tmp);
+                    if (tmp <= b) { c = b; b = tmp; bInd = p; }
+                    else if (tmp > b && tmp <= c) { c = tmp; }
+                }
+                if (bInd < 0 && hi > lo && undefined_frames) undefined_frames[f] = 1;
+                a = cl_sign(a);
+                for (int32_t p = lo; p < hi; ++p) lR[p] *= (p == bInd) ? a * c : a * b;
+            }
+            for (int32_t n = 0; n < N; ++n) {               /* :515-531 */
+                float tmp = yf[n];
+                for (int32_t p = g->col_ptr[n]; p < g->col_ptr[n + 1]; ++p) tmp += lR[g->col_edge[p]];
+                lP[n] = tmp;
+            }
+            for (int32_t n = 0; n < N; ++n) src[n] = lP[n] < 0;      /* :540-541 */
+            const int flag = syndrome_fails(g, src);                 /* :545-553 */
+            ++time;
+            if (taps && taps->iter == time) {
+                tap_copy(taps->r, f, E, lR);
+                tap_copy(taps->post, f, N, lP);
+            }
+            if (!flag) break;
+            if (time == max_iter) break;
+        }
+        if (iters) iters[f] = time;
+        if (hard_out) memcpy(hard_out + f * N, src, (size_t)N);
+        pack_frame(g, src, f, pack_mode, out, out_bytes);
+    }
+    free(lP); free(lR); free(src);
+    return 0;
+}
+
 /* ------------------------------------------------------------ test channel */
 
 /* gaussian(), MyLdpc.cpp:1093-1105: Box-Muller on libc rand(), pi truncated to

@@ -107,6 +107,12 @@ int oracle_decode_layered(const oracle_graph *g, int32_t layer_rows, const float
                           int64_t out_bytes, int32_t *iters, uint8_t *hard_out,
                           const oracle_taps *taps, uint8_t *undefined_frames);
 
+/* Fused flooding min-sum with the arithmetic of decodeOnceMS, decodeCL.c:432-567
+ * (DecodeMSCL; the reference hard-codes 120 iterations). */
+int oracle_decode_ms_fused(const oracle_graph *g, const float *y, int64_t frames, int max_iter,
+                           int pack_mode, uint8_t *out, int64_t out_bytes, int32_t *iters,
+                           uint8_t *hard_out, const oracle_taps *taps, uint8_t *undefined_frames);
+
 /* Length helpers, MyLdpc.cpp:620-631. */
 int64_t oracle_code_size(int64_t src_length, int32_t K);
 

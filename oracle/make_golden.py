@@ -48,6 +48,17 @@ LAYERED_CASES = [
 ]
 
 
+# fused flooding kernel decodeOnceMS (DecodeMSCL): times fixed at 120; same shift restrictions
+MSCL_CASES = [
+    ("m576_12", 0, 576, 0.80, 6, 31),
+    ("m576_12_hard", 0, 576, 1.00, 3, 32),
+    ("m576_34a", 3, 576, 0.60, 4, 33),
+    ("m960_23b", 2, 960, 0.70, 3, 34),
+    ("m1152_56", 5, 1152, 0.45, 3, 35),
+    ("m2304_12", 0, 2304, 0.85, 2, 36),
+]
+
+
 def channel(N, frames, sigma, seed):
     rng = np.random.Generator(np.random.Philox(key=[20260101, seed]))
     return (1.0 + sigma * rng.standard_normal((frames, N))).astype(np.float32)
@@ -82,6 +93,15 @@ def main():
         np.savez_compressed(os.path.join(OUT, "layered_%s.npz" % name), rate=rate, N=N, K=K, z=z,
                             sigma=sigma, times=40, y=y, out=out)
         print("layered", name, "z", z)
+    for name, rate, N, sigma, B, seed in MSCL_CASES:
+        z = N // 24
+        mb = len(SEEDS[rate])
+        K = N - mb * z
+        y = channel(N, B, sigma, seed)
+        out = rk.decode_mscl_fused(z, np.array(SEEDS[rate], np.int8), y)
+        np.savez_compressed(os.path.join(OUT, "mscl_%s.npz" % name), rate=rate, N=N, K=K, z=z,
+                            sigma=sigma, times=120, y=y, out=out)
+        print("mscl", name, "z", z)
     # graph construction facts the survey measured on the reference's own H builder
     # (E printed by the reference's initCheckMatrix + adjacency build)
     np.savez_compressed(os.path.join(OUT, "graph_facts.npz"),

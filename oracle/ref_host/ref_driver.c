@@ -50,6 +50,9 @@ void toChar(bool *srcBool, char *srcCode, const int ldpcN, const int ldpcK);
 void decodeOnceTDMP(float *postCode, char *srcCode, const char z, const char seedRowLength,
                     const char *hSeed, float *lP, bool *srcBool, bool *flag);
 
+void decodeOnceMS(float *postCode, char *srcCode, const char z, const char seedRowLength, char *hSeed,
+                  float *lP, float *lR, bool *srcBool, bool *flag);
+
 #define NDRANGE2(B, G, CALL)                                   \
     for (int b_ = 0; b_ < (B); ++b_)                           \
         for (int g_ = 0; g_ < (G); ++g_) {                     \
@@ -212,5 +215,61 @@ int ref_decode_tdmp(int z, int seedRows, const char *hSeed, float *postCode, int
         pthread_barrier_destroy(&start);
     }
     free(th); free(args); free(lP); free(srcBool);
+    return 0;
+}
+
+/* Fused flooding kernel decodeOnceMS (decodeCL.c:432-567), launched as Coder::decodeOnceMSCL does
+ * (MyLdpc.cpp:877-879): global (B*z, M/z), local (z, M/z): one work-group of M work-items per
+ * frame.  Local buffers as MyLdpc.cpp:543-547: lP[N], lR[M*24], srcBool[N], flag. */
+typedef struct {
+    int group, lid, z, seedRows;
+    float *postCode; char *srcCode; char *hSeed;
+    float *lP, *lR; bool *srcBool; bool *flag;
+    pthread_barrier_t *bar;
+} ms_arg;
+
+static void *ms_main(void *p)
+{
+    ms_arg *a = (ms_arg *)p;
+    clh_group_id[0] = a->group;
+    clh_local_id[0] = a->lid % a->z;
+    clh_local_id[1] = a->lid / a->z;
+    clh_global_id[0] = a->group * a->z + clh_local_id[0];
+    clh_global_id[1] = clh_local_id[1];
+    clh_group_barrier = a->bar;
+    clh_start_barrier = NULL;
+    decodeOnceMS(a->postCode, a->srcCode, (char)a->z, (char)a->seedRows, a->hSeed, a->lP, a->lR,
+                 a->srcBool, a->flag);
+    return NULL;
+}
+
+int ref_decode_mscl(int z, int seedRows, char *hSeed, float *postCode, int B, char *srcCode)
+{
+    const int N = 24 * z, M = seedRows * z;
+    if (z > 127 || N > 32767) return -1;
+    pthread_t *th = malloc(sizeof(pthread_t) * (size_t)M);
+    ms_arg *args = malloc(sizeof(ms_arg) * (size_t)M);
+    float *lP = malloc(sizeof(float) * (size_t)N);
+    float *lR = malloc(sizeof(float) * (size_t)M * 24);
+    bool *srcBool = malloc((size_t)N), flag[1];
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setstacksize(&attr, 256 * 1024);
+    for (int b = 0; b < B; ++b) {
+        pthread_barrier_t bar;
+        pthread_barrier_init(&bar, NULL, (unsigned)M);
+        memset(srcBool, 0, (size_t)N);
+        memset(lR, 0, sizeof(float) * (size_t)M * 24);
+        flag[0] = 0;
+        for (int l = 0; l < M; ++l) {
+            ms_arg a = { b, l, z, seedRows, postCode, srcCode, hSeed, lP, lR, srcBool, flag, &bar };
+            args[l] = a;
+            if (pthread_create(&th[l], &attr, ms_main, &args[l])) return -2;
+        }
+        for (int l = 0; l < M; ++l) pthread_join(th[l], NULL);
+        pthread_barrier_destroy(&bar);
+    }
+    pthread_attr_destroy(&attr);
+    free(th); free(args); free(lP); free(lR); free(srcBool);
     return 0;
 }

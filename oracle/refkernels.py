@@ -45,6 +45,9 @@ def lib():
             f.restype = ctypes.c_int
             f.argtypes = [ctypes.POINTER(_RefGraph), _fp, ctypes.c_int, ctypes.c_int,
                           ctypes.c_char_p, _u8p, _u8p, ctypes.POINTER(_RefTaps)]
+        L.ref_decode_mscl.restype = ctypes.c_int
+        L.ref_decode_mscl.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, _fp, ctypes.c_int,
+                                      ctypes.c_char_p]
         L.ref_decode_tdmp.restype = ctypes.c_int
         L.ref_decode_tdmp.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, _fp,
                                       ctypes.c_int, ctypes.c_char_p]
@@ -130,4 +133,21 @@ def decode_tdmp_fused(z, seed, y):
                            y.ctypes.data_as(_fp), B, out.ctypes.data_as(ctypes.c_char_p))
     if rc:
         raise RuntimeError("ref_decode_tdmp rc=%d" % rc)
+    return out
+
+
+def decode_mscl_fused(z, seed, y):
+    """Run the fused flooding kernel decodeOnceMS (times fixed at 120, floor-scaled shifts,
+    z <= 127): one host thread per work-item, M = rows of H per frame.  Returns packed bytes."""
+    L = lib()
+    seed = np.ascontiguousarray(seed, np.int8)
+    N = 24 * z
+    K = N - seed.shape[0] * z
+    y = np.ascontiguousarray(y, np.float32).reshape(-1, N)
+    B = y.shape[0]
+    out = np.zeros((B - 1) * K // 8 + K // 8, np.uint8)
+    rc = L.ref_decode_mscl(z, seed.shape[0], seed.ctypes.data_as(ctypes.c_char_p),
+                           y.ctypes.data_as(_fp), B, out.ctypes.data_as(ctypes.c_char_p))
+    if rc:
+        raise RuntimeError("ref_decode_mscl rc=%d" % rc)
     return out

@@ -1,6 +1,6 @@
 // Round-trip harness in the shape of the reference's only test, Test.cpp:15-118:
 //   payload 'a'+i%26 -> encode -> AWGN (sd = 10^(-snr/20)) -> decode -> ErrNum / ThroughPut.
-// Usage: coder_roundtrip <rate 0..5> <N> <srcBytes> <batch> <snr_dB> <SP|MS|CPU|TDMP|TDMPCL|ENC> [seed]
+// Usage: coder_roundtrip <rate 0..5> <N> <srcBytes> <batch> <snr_dB> <SP|MS|CPU|TDMP|TDMPCL|MSCL|ENC> [seed]
 // ENC: encoder only (no GPU): checks H c = 0 for every frame and prints "ParityFail=<n>".
 // Prints the reference's fields (sd=, Time=, <MODE>:<seconds>, ErrNum=, ThroughPut=).
 #include <cmath>
@@ -64,6 +64,7 @@ int main(int argc, char **argv)
     else if (!strcmp(mode, "CPU")) t = DecodeCPU;
     else if (!strcmp(mode, "TDMP")) t = DecodeTDMP;
     else if (!strcmp(mode, "TDMPCL")) t = DecodeTDMPCL;
+    else if (!strcmp(mode, "MSCL")) t = DecodeMSCL;
     else return 2;
     if (coder.addDecodeType(t)) { cout << "addDecodeType failed: " << coder.lastError() << endl; return 1; }
     struct timespec t0, t1;

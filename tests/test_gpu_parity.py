@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FLOOD = golden_files("flood")
 LAYERED = golden_files("layered")
+MSCL = golden_files("mscl")
 f32 = np.float32
 
 
@@ -95,6 +96,27 @@ def test_layered_bit_exact_vs_fused_reference_kernel(built, path, V):
     run = np.nonzero(o["iters"] >= 2)[0]
     assert np.array_equal(dec.dump(0, y.shape[0])[run], o["taps"]["r"][run])
     assert np.array_equal(dec.dump(2, y.shape[0])[run], o["taps"]["post"][run])
+    dec.close()
+
+
+@pytest.mark.parametrize("path", MSCL, ids=lambda p: p.split("mscl_")[-1][:-4])
+def test_fused_flooding_bit_exact_vs_reference_kernel(built, path):
+    """LDPC_ALGO_MS_FUSED (DecodeMSCL) against the reference's decodeOnceMS kernel outputs and
+    the oracle's iteration counts / messages."""
+    gd = load_golden(path)
+    g, og, K, M, z = _graph(int(gd["rate"]), int(gd["N"]))
+    y = gd["y"]
+    B = y.shape[0]
+    dec = L.Decoder(g, K, max_batch=B, algo="ms_fused", max_iter=120, layer_rows=z)
+    out, iters = dec.decode(y)
+    assert np.array_equal(out, gd["out"])
+    o = oracle.decode(og, y, "ms_fused", max_iter=120, tap_iter=2)
+    assert np.array_equal(iters, o["iters"])
+    dec.set_tap(2)
+    dec.decode(y)
+    run = np.nonzero(o["iters"] >= 2)[0]
+    assert np.array_equal(dec.dump(0, B)[run], o["taps"]["r"][run])
+    assert np.array_equal(dec.dump(2, B)[run], o["taps"]["post"][run])
     dec.close()
 
 
@@ -292,7 +314,7 @@ def test_cpp_coder_round_trip_like_test_cpp(built, tmp_path):
                            os.path.join(ROOT, "tests", "cpp", "coder_roundtrip.cpp"), "-o", exe,
                            "-L" + os.path.join(ROOT, "myldpccppapi_amd"), "-lmyldpc", "-lldpc_hip",
                            "-Wl,-rpath," + os.path.join(ROOT, "myldpccppapi_amd")])
-    for mode in ("SP", "MS", "CPU", "TDMP", "TDMPCL"):
+    for mode in ("SP", "MS", "CPU", "TDMP", "TDMPCL", "MSCL"):
         # Test.cpp's code: z = 24, rate 3/4B; 10 kB payload, batch 64, 6 dB
         out = subprocess.run([exe, "4", "576", "10000", "64", "6", mode], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr

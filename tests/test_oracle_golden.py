@@ -8,6 +8,7 @@ from util import assert_taps_equal, golden_files, load_golden, wimax_oracle_grap
 
 FLOOD = golden_files("flood")
 LAYERED = golden_files("layered")
+MSCL = golden_files("mscl")
 
 
 def test_fixtures_present():
@@ -46,6 +47,16 @@ def test_layered_matches_fused_reference_kernel(path):
     g, rows, cols, K, M, z = wimax_oracle_graph(int(gd["rate"]), int(gd["N"]))
     o = oracle.decode(g, gd["y"], "layered", max_iter=int(gd["times"]), layer_rows=z)
     # frames on which the reference reads an uninitialised variable are outside the contract
+    assert not o["undefined"].any()
+    assert np.array_equal(o["out"], gd["out"])
+
+
+@pytest.mark.parametrize("path", MSCL, ids=lambda p: p.split("mscl_")[-1][:-4])
+def test_fused_flooding_matches_reference_kernel(path):
+    """decodeOnceMS (DecodeMSCL): product sign, 1000/1001 two-minimum rule, 120 iterations."""
+    gd = load_golden(path)
+    g, rows, cols, K, M, z = wimax_oracle_graph(int(gd["rate"]), int(gd["N"]))
+    o = oracle.decode(g, gd["y"], "ms_fused", max_iter=int(gd["times"]))
     assert not o["undefined"].any()
     assert np.array_equal(o["out"], gd["out"])
 
