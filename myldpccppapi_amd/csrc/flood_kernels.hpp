@@ -584,7 +584,8 @@ __global__ __launch_bounds__(kBlock) void check_link_kernel(const CheckArgs a, c
 
 /* The variable node keeps WIDE waves (V values per lane, whole 64*V-frame segments per
  * wave-instruction): narrow waves as in check_kernel were measured 10 % slower here
- * (1.69 vs 1.53 ms per round at B = 4096) -- the gather prefers fewer, larger requests. */
+ * (1.69 vs 1.53 ms per round at B = 4096), 2 values per lane no faster (1.11 vs 1.12 ms) --
+ * the gather prefers fewer, larger requests. */
 template <int ALGO, int D, int V, typename T>
 __global__ __launch_bounds__(kBlock) void var_kernel(const VarArgs a)
 {

@@ -346,9 +346,9 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
                       d->E, d->N, cc.count, 1, (it < max_iter) ? 1 : 0, cc.degree};
             const int cpw = d->tune_cpw ? d->tune_cpw : 1;
             a.cols_per_wave = cpw;
+            const int slotk = cc.degree <= kMaxUnrolledDegree ? cc.degree : 0;
             const int waves = (cc.count + cpw - 1) / cpw;
             dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
-            const int slotk = cc.degree <= kMaxUnrolledDegree ? cc.degree : 0;
             d->var_fn[slotk]<<<grid, kBlock, 0, s>>>(a);
             HIP_TRY(span_end(d, s));
         }

@@ -139,3 +139,25 @@ def test_layered_bg1_profile_z384(built):
     assert np.array_equal(out0[:kb], o["out"][:kb]) and np.array_equal(out0[69 * kb:], o["out"][kb:])
     assert it0[0] == o["iters"][0] and it0[69] == o["iters"][1]
     dec.close()
+
+
+def test_full_batch_4096_frames_indexing(built, code):
+    """configs[1] at its real size: 4096 frames = 16 tiles of 256, message arrays of 3.7 GB each
+    (element offsets beyond 2^31).  Sum-product, 12 iterations; frames from the first, a middle
+    and the last tile are checked bit for bit against the oracle, and every frame must report
+    the iteration count the oracle's sample shows for non-converging noise."""
+    rows, cols, g, og = code
+    B = 4096
+    rng = np.random.default_rng(77)
+    y = (1.0 + 0.95 * rng.standard_normal((B, N), dtype=np.float32)).astype(np.float32)
+    dec = L.Decoder(g, K, max_batch=B, algo="sp", max_iter=12)
+    out, iters = dec.decode(y)
+    pick = [0, 255, 2048 + 77, 4095 - 256, 4095]
+    o = oracle.decode(og, y[pick], "sp", max_iter=12)
+    kb = K // 8
+    for i, f in enumerate(pick):
+        assert np.array_equal(out[f * kb:(f + 1) * kb], o["out"][i * kb:(i + 1) * kb]), f
+        assert iters[f] == o["iters"][i]
+    assert (iters == 12).all() and dec.stats()["frames_converged"] == 0
+    dec.close()
+    del y

@@ -175,6 +175,41 @@ def test_k_not_byte_aligned_and_bit_packing(built, algo):
         dec.close()
 
 
+@pytest.mark.parametrize("algo", ["ms", "sp", "layered", "ms_fused"])
+def test_degenerate_channel_values(built, algo, monkeypatch):
+    """Erasures (y = 0), huge values (exp overflows to inf -> inf/inf = NaN in the SP priors),
+    infinities, NaNs, denormals and exact ties: whatever the reference's arithmetic makes of
+    them, the HIP path must make the same of them."""
+    rate, N = codes.RATE_1_2, 960
+    g, og, K, M, z = _graph(rate, N)
+    rng = np.random.default_rng(21)
+    y = channel.awgn_frames(N, 0, 24, 0.7, seed=21)
+    y[0, rng.choice(N, 200, replace=False)] = 0.0                 # erasures
+    y[1, :] = 0.0                                                 # everything erased
+    y[2, rng.choice(N, 50, replace=False)] = 12.0                 # exp(96) = inf
+    y[3, rng.choice(N, 50, replace=False)] = -30.0
+    y[4, rng.choice(N, 20, replace=False)] = np.inf
+    y[5, rng.choice(N, 20, replace=False)] = -np.inf
+    y[6, rng.choice(N, 5, replace=False)] = np.nan
+    y[7, rng.choice(N, 100, replace=False)] = 1e-41               # denormal
+    y[8, :] = 1.0                                                 # noiseless, all ties in min-sum
+    y[9, :] = -1.0
+    y[10, rng.choice(N, 300, replace=False)] *= 400.0             # magnitudes beyond the 1000 clip
+    y[11, ::2] = 0.0
+    for fused in (("1", "0") if algo == "layered" else ("1",)):
+        monkeypatch.setenv("LDPC_TUNE_FUSED", fused)
+        dec = L.Decoder(g, K, max_batch=24, algo=algo, max_iter=15, layer_rows=z)
+        out, iters = dec.decode(y)
+        want = oracle.decode(og, y, algo, max_iter=15, layer_rows=z)
+        ok = np.ones(24, bool)
+        if "undefined" in want:           # rows with every |Q| > 1000: undefined in the reference kernel
+            ok = want["undefined"] == 0
+        kb = K // 8
+        assert np.array_equal(out.reshape(24, kb)[ok], want["out"].reshape(24, kb)[ok]), (algo, fused)
+        assert np.array_equal(iters[ok], want["iters"][ok]), (algo, fused)
+        dec.close()
+
+
 def test_parameters_follow_the_oracle(built):
     g, og, K, M, z = _graph(codes.RATE_1_2, 1152)
     y = channel.awgn_frames(1152, 0, 40, 0.85, seed=6)
