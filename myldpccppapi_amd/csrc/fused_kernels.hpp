@@ -29,6 +29,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "layered_kernels.hpp"
@@ -47,6 +49,11 @@ struct FusedArgs {
     const int32_t *__restrict__ ent_bc;   /* block column of entry */
     const int32_t *__restrict__ ent_sh;   /* circulant shift of entry */
     const int32_t *__restrict__ layer_e0; /* [layers] edge id of the layer's first edge */
+    const int32_t *__restrict__ ent_pack; /* [layers][pack_w]: (block column << 16) | shift, padded: ONE wide
+                                             scalar load per layer instead of two per edge (the per-edge
+                                             scalar loads, ~45 serialised K$ round trips per layer step,
+                                             were what bounded the first version of these kernels) */
+    int32_t pack_w;
     /* column view for the flooding variant: block column bc is met by entries
      * bcol_ptr[bc]..bcol_ptr[bc+1], ascending layer = ascending row */
     const int32_t *__restrict__ bcol_ptr; /* [N/z + 1] */
@@ -56,8 +63,113 @@ struct FusedArgs {
     int32_t N, E, K, z, layers, max_iter, rounds, early_term;
 };
 
+/* One row of one layer (decodeCL.c:345-383) for lane-row r.  DMAX > 0: the row's d <= DMAX
+ * inputs are requested from LDS back to back (a row's columns are distinct, rows of a layer
+ * share none, so nothing aliases), the product / two-minimum chain runs in registers, and the
+ * results are stored once.  The run-time loop version (DMAX == 0) re-reads P between its two
+ * passes like the reference; it serialises ~2d LDS round trips per row and was the reason the
+ * first fused kernel ran no faster than streaming HBM at full work.  Same values either way. */
+template <int DMAX>
+__device__ __forceinline__ void fused_layer_row(float *P, float *Rl, const int32_t *bc, const int32_t *sh,
+                                                const int32_t *pk, int d, int z, int r)
+{
+    if (DMAX == 0) {
+        float prod = 1.0f, b = 1000.0f, c = 1001.0f;   /* decodeCL.c:346-348 */
+        int bind = -1;
+        for (int k = 0; k < d; ++k) {                  /* :350-367 */
+            int t = r + sh[k];
+            t = t >= z ? t - z : t;
+            const int col = bc[k] * z + t;
+            const float q = P[col] - Rl[k * z + r];
+            prod *= q;
+            P[col] = q;                                /* :357 parks q in lP */
+            const float mag = __builtin_fabsf(q);
+            if (mag <= b) { c = b; b = mag; bind = k; }
+            else if (mag > b && mag <= c) { c = mag; }
+        }
+        const float sa = cl_sign(prod);                /* :369 */
+        const float ab = sa * b, ac = sa * c;
+        for (int k = 0; k < d; ++k) {                  /* :371-383 */
+            int t = r + sh[k];
+            t = t >= z ? t - z : t;
+            const int col = bc[k] * z + t;
+            const float q = P[col];
+            const float rn = cl_sign(q) * ((k == bind) ? ac : ab);
+            Rl[k * z + r] = rn;
+            P[col] = q + rn;
+        }
+        return;
+    }
+    constexpr int DM = DMAX > 0 ? DMAX : 1;
+    float q[DM];
+    int col[DM], ent[DM];
+#pragma unroll
+    for (int k = 0; k < DM; ++k) ent[k] = pk[k];           /* unconditional, contiguous: s_load_dwordxN */
+#pragma unroll
+    for (int k = 0; k < DM; ++k) {
+        int t = r + (ent[k] & 0xffff);
+        t = t >= z ? t - z : t;
+        col[k] = (ent[k] >> 16) * z + t;
+    }
+#pragma unroll
+    for (int k = 0; k < DM; ++k)
+        if (k < d) q[k] = P[col[k]] - Rl[k * z + r];
+    float prod = 1.0f, b = 1000.0f, c = 1001.0f;
+    int bind = -1;
+#pragma unroll
+    for (int k = 0; k < DM; ++k) {
+        if (k < d) {
+            prod *= q[k];
+            const float mag = __builtin_fabsf(q[k]);
+            if (mag <= b) { c = b; b = mag; bind = k; }
+            else if (mag > b && mag <= c) { c = mag; }
+        }
+    }
+    const float sa = cl_sign(prod);
+    const float ab = sa * b, ac = sa * c;
+#pragma unroll
+    for (int k = 0; k < DM; ++k) {
+        if (k < d) {
+            const float rn = cl_sign(q[k]) * ((k == bind) ? ac : ab);
+            Rl[k * z + r] = rn;
+            P[col[k]] = q[k] + rn;
+        }
+    }
+}
+
+/* Row parity of the hard decisions P < 0 (decodeCL.c:393-404), loads first as above. */
+template <int DMAX>
+__device__ __forceinline__ int fused_row_parity(const float *P, const int32_t *bc, const int32_t *sh,
+                                                const int32_t *pk, int d, int z, int r)
+{
+    int par = 0;
+    if (DMAX == 0) {
+        for (int k = 0; k < d; ++k) {
+            int t = r + sh[k];
+            t = t >= z ? t - z : t;
+            par ^= (P[bc[k] * z + t] < 0.0f) ? 1 : 0;
+        }
+        return par;
+    }
+    constexpr int DM = DMAX > 0 ? DMAX : 1;
+    float v[DM];
+    int ent[DM];
+#pragma unroll
+    for (int k = 0; k < DM; ++k) ent[k] = pk[k];
+#pragma unroll
+    for (int k = 0; k < DM; ++k) {
+        int t = r + (ent[k] & 0xffff);
+        t = t >= z ? t - z : t;
+        v[k] = P[(ent[k] >> 16) * z + t];                  /* padded entries repeat entry 0: valid address */
+    }
+#pragma unroll
+    for (int k = 0; k < DM; ++k)
+        if (k < d) par ^= (v[k] < 0.0f) ? 1 : 0;
+    return par;
+}
+
 /* One workgroup = one frame = MW waves (MW = ceil(z/64)); MW == 1 needs no barriers. */
-template <int MW>
+template <int MW, int DMAX>
 __global__ __launch_bounds__(64 * MW) void fused_layered_kernel(const FusedArgs a)
 {
     extern __shared__ float lds[];
@@ -92,32 +204,7 @@ __global__ __launch_bounds__(64 * MW) void fused_layered_kernel(const FusedArgs 
         for (int l = 0; l < a.layers; ++l) {
             const int p0 = a.layer_ptr[l], d = a.layer_ptr[l + 1] - p0;
             float *Rl = R + a.layer_e0[l];              /* [d][z] */
-            if (r < z) {
-                float prod = 1.0f, b = 1000.0f, c = 1001.0f;   /* decodeCL.c:346-348 */
-                int bind = -1;
-                for (int k = 0; k < d; ++k) {                  /* :350-367 */
-                    int t = r + a.ent_sh[p0 + k];
-                    t = t >= z ? t - z : t;
-                    const int col = a.ent_bc[p0 + k] * z + t;
-                    const float q = P[col] - Rl[k * z + r];
-                    prod *= q;
-                    P[col] = q;                                /* :357 parks q in lP */
-                    const float mag = __builtin_fabsf(q);
-                    if (mag <= b) { c = b; b = mag; bind = k; }
-                    else if (mag > b && mag <= c) { c = mag; }
-                }
-                const float sa = cl_sign(prod);                /* :369 */
-                const float ab = sa * b, ac = sa * c;
-                for (int k = 0; k < d; ++k) {                  /* :371-383 */
-                    int t = r + a.ent_sh[p0 + k];
-                    t = t >= z ? t - z : t;
-                    const int col = a.ent_bc[p0 + k] * z + t;
-                    const float q = P[col];
-                    const float rn = cl_sign(q) * ((k == bind) ? ac : ab);
-                    Rl[k * z + r] = rn;
-                    P[col] = q + rn;
-                }
-            }
+            if (r < z) fused_layer_row<DMAX>(P, Rl, a.ent_bc + p0, a.ent_sh + p0, a.ent_pack + (size_t)l * a.pack_w, d, z, r);
             sync();                                            /* :385 */
         }
         /* bits = P < 0, row parities (decodeCL.c:387-404) */
@@ -125,13 +212,7 @@ __global__ __launch_bounds__(64 * MW) void fused_layered_kernel(const FusedArgs 
         if (r < z) {
             for (int l = 0; l < a.layers; ++l) {
                 const int p0 = a.layer_ptr[l], d = a.layer_ptr[l + 1] - p0;
-                int par = 0;
-                for (int k = 0; k < d; ++k) {
-                    int t = r + a.ent_sh[p0 + k];
-                    t = t >= z ? t - z : t;
-                    par ^= (P[a.ent_bc[p0 + k] * z + t] < 0.0f) ? 1 : 0;
-                }
-                bad |= par;
+                bad |= fused_row_parity<DMAX>(P, a.ent_bc + p0, a.ent_sh + p0, a.ent_pack + (size_t)l * a.pack_w, d, z, r);
             }
         }
         const int any_bad = (MW == 1) ? (__ballot(bad != 0) != 0ull) : __syncthreads_or(bad);
@@ -173,13 +254,150 @@ __global__ __launch_bounds__(64 * MW) void fused_layered_kernel(const FusedArgs 
     }
 }
 
+/* z <= 32: G = 64 / z frames share one wave (lanes [g*z, (g+1)*z) = frame g's rows), so a
+ * z = 24 code (the reference's own Test.cpp configuration) uses 48 of 64 lanes instead of 24.
+ * Each frame keeps its own LDS image and leaves the loop on its own clean syndrome (its lanes
+ * go idle); the wave runs until its last frame is done.  Same arithmetic, same results. */
+template <int DMAX>
+__global__ __launch_bounds__(64) void fused_layered_packed_kernel(const FusedArgs a, const int G)
+{
+    extern __shared__ float lds[];
+    const int lane = (int)threadIdx.x;
+    const int z = a.z;
+    const int g = lane / z;
+    const int r = lane - g * z;
+    const int64_t frame = (int64_t)blockIdx.x * G + g;
+    const bool mine = g < G && frame < a.frames;             /* lane belongs to a real frame */
+    float *P = lds + (size_t)(mine ? g : 0) * (a.N + a.E);
+    float *R = P + a.N;
+    auto sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    if (mine) {
+        const float *y = a.llr + (size_t)frame * a.N;
+        for (int n = r; n < a.N; n += z) P[n] = y[n];
+        for (int e = r; e < a.E; e += z) R[e] = 0.0f;
+    }
+    sync();
+    const uint64_t grp_mask = (z >= 64 ? ~0ull : ((1ull << z) - 1ull)) << (g < G ? g * z : 0);
+    int time = 0, my_iters = a.max_iter;
+    bool active = mine, clean = false;
+    while (__ballot(active) != 0ull) {
+        for (int l = 0; l < a.layers; ++l) {
+            const int p0 = a.layer_ptr[l], d = a.layer_ptr[l + 1] - p0;
+            float *Rl = R + a.layer_e0[l];
+            if (active) fused_layer_row<DMAX>(P, Rl, a.ent_bc + p0, a.ent_sh + p0, a.ent_pack + (size_t)l * a.pack_w, d, z, r);
+            sync();
+        }
+        int bad = 0;
+        if (active) {
+            for (int l = 0; l < a.layers; ++l) {
+                const int p0 = a.layer_ptr[l], d = a.layer_ptr[l + 1] - p0;
+                bad |= fused_row_parity<DMAX>(P, a.ent_bc + p0, a.ent_sh + p0, a.ent_pack + (size_t)l * a.pack_w, d, z, r);
+            }
+        }
+        const uint64_t bad_mask = __ballot(bad != 0);
+        ++time;
+        if (active) {
+            clean = (bad_mask & grp_mask) == 0ull;
+            if ((clean && a.early_term) || time == a.rounds) {
+                active = false;
+                my_iters = clean ? time : a.max_iter;
+            }
+        }
+        sync();
+    }
+    if (!mine) return;
+    const int64_t base = frame * (int64_t)a.K / 8;
+    for (int j = r; j < a.K / 8; j += z) {
+        unsigned byte = 0;
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) byte |= (P[j * 8 + bit] < 0.0f ? 1u : 0u) << bit;
+        if (base + j < a.out_bytes) a.out[base + j] = (uint8_t)byte;
+    }
+    if (a.dump_p)
+        for (int n = r; n < a.N; n += z) a.dump_p[(size_t)frame * a.N + n] = P[n];
+    if (a.dump_r) {
+        for (int l = 0; l < a.layers; ++l) {
+            const int d = a.layer_ptr[l + 1] - a.layer_ptr[l], e0 = a.layer_e0[l];
+            for (int i = r; i < d * z; i += z) {
+                const int rr = i / d, k = i % d;
+                a.dump_r[(size_t)frame * a.E + e0 + i] = R[e0 + k * z + rr];
+            }
+        }
+    }
+    if (r == 0) {
+        if (a.iters) a.iters[frame] = my_iters;
+        atomicMax(&a.summary[0], my_iters);
+        if (clean) atomicAdd(&a.summary[1], 1);
+    }
+}
+
+/* Flooding row (decodeCL.c:482-512): R_k = sign(q_k) * sign(prod) * (k == argmin ? min2 : min1)
+ * with q_k = P[col_k] - R_k; P is only read. */
+template <int DMAX>
+__device__ __forceinline__ void fused_flood_row(const float *P, float *Rl, const int32_t *bc, const int32_t *sh,
+                                                const int32_t *pk, int d, int z, int r)
+{
+    if (DMAX == 0) {
+        float prod = 1.0f, b = 1000.0f, c = 1001.0f;
+        int bind = -1;
+        for (int k = 0; k < d; ++k) {                  /* :486-501 */
+            int t = r + sh[k];
+            t = t >= z ? t - z : t;
+            const float q = P[bc[k] * z + t] - Rl[k * z + r];
+            Rl[k * z + r] = cl_sign(q);
+            prod *= q;
+            const float mag = __builtin_fabsf(q);
+            if (mag <= b) { c = b; b = mag; bind = k; }
+            else if (mag > b && mag <= c) { c = mag; }
+        }
+        const float sa = cl_sign(prod);                /* :502 */
+        const float ab = sa * b, ac = sa * c;
+        for (int k = 0; k < d; ++k)                    /* :504-513 */
+            Rl[k * z + r] = Rl[k * z + r] * ((k == bind) ? ac : ab);
+        return;
+    }
+    constexpr int DM = DMAX > 0 ? DMAX : 1;
+    float q[DM];
+    int col[DM], ent[DM];
+#pragma unroll
+    for (int k = 0; k < DM; ++k) ent[k] = pk[k];
+#pragma unroll
+    for (int k = 0; k < DM; ++k) {
+        int t = r + (ent[k] & 0xffff);
+        t = t >= z ? t - z : t;
+        col[k] = (ent[k] >> 16) * z + t;
+    }
+#pragma unroll
+    for (int k = 0; k < DM; ++k)
+        if (k < d) q[k] = P[col[k]] - Rl[k * z + r];
+    float prod = 1.0f, b = 1000.0f, c = 1001.0f;
+    int bind = -1;
+#pragma unroll
+    for (int k = 0; k < DM; ++k) {
+        if (k < d) {
+            prod *= q[k];
+            const float mag = __builtin_fabsf(q[k]);
+            if (mag <= b) { c = b; b = mag; bind = k; }
+            else if (mag > b && mag <= c) { c = mag; }
+        }
+    }
+    const float sa = cl_sign(prod);
+    const float ab = sa * b, ac = sa * c;
+#pragma unroll
+    for (int k = 0; k < DM; ++k)
+        if (k < d) Rl[k * z + r] = cl_sign(q[k]) * ((k == bind) ? ac : ab);
+}
+
 /* Flooding counterpart: the reference's fused kernel decodeOnceMS (decodeCL.c:432-567,
  * DecodeMSCL).  Every iteration: all rows from the same posteriors (check node with the
  * product sign and the 1000/1001 two-minimum rule, :482-512), then every posterior rebuilt
  * as y + sum of its column's R in ascending row order (:515-531), bits = P < 0, syndrome.
  * Same LDS layout and lane mapping as fused_layered_kernel; y is re-read from global memory
  * (L2) instead of being kept in LDS. */
-template <int MW>
+template <int MW, int DMAX>
 __global__ __launch_bounds__(64 * MW) void fused_flood_kernel(const FusedArgs a)
 {
     extern __shared__ float lds[];
@@ -208,23 +426,7 @@ __global__ __launch_bounds__(64 * MW) void fused_flood_kernel(const FusedArgs a)
         if (r < z) {
             for (int l = 0; l < a.layers; ++l) {               /* rows never touch P here */
                 const int p0 = a.layer_ptr[l], d = a.layer_ptr[l + 1] - p0;
-                float *Rl = R + a.layer_e0[l];
-                float prod = 1.0f, b = 1000.0f, c = 1001.0f;
-                int bind = -1;
-                for (int k = 0; k < d; ++k) {                  /* :486-501 */
-                    int t = r + a.ent_sh[p0 + k];
-                    t = t >= z ? t - z : t;
-                    const float q = P[a.ent_bc[p0 + k] * z + t] - Rl[k * z + r];
-                    Rl[k * z + r] = cl_sign(q);
-                    prod *= q;
-                    const float mag = __builtin_fabsf(q);
-                    if (mag <= b) { c = b; b = mag; bind = k; }
-                    else if (mag > b && mag <= c) { c = mag; }
-                }
-                const float sa = cl_sign(prod);                /* :502 */
-                const float ab = sa * b, ac = sa * c;
-                for (int k = 0; k < d; ++k)                    /* :504-513 */
-                    Rl[k * z + r] = Rl[k * z + r] * ((k == bind) ? ac : ab);
+                fused_flood_row<DMAX>(P, R + a.layer_e0[l], a.ent_bc + p0, a.ent_sh + p0, a.ent_pack + (size_t)l * a.pack_w, d, z, r);
             }
         }
         sync();                                                /* :514 */
@@ -243,13 +445,7 @@ __global__ __launch_bounds__(64 * MW) void fused_flood_kernel(const FusedArgs a)
         if (r < z) {
             for (int l = 0; l < a.layers; ++l) {
                 const int p0 = a.layer_ptr[l], d = a.layer_ptr[l + 1] - p0;
-                int par = 0;
-                for (int k = 0; k < d; ++k) {
-                    int t = r + a.ent_sh[p0 + k];
-                    t = t >= z ? t - z : t;
-                    par ^= (P[a.ent_bc[p0 + k] * z + t] < 0.0f) ? 1 : 0;
-                }
-                bad |= par;
+                bad |= fused_row_parity<DMAX>(P, a.ent_bc + p0, a.ent_sh + p0, a.ent_pack + (size_t)l * a.pack_w, d, z, r);
             }
         }
         const int any_bad = (MW == 1) ? (__ballot(bad != 0) != 0ull) : __syncthreads_or(bad);
@@ -288,9 +484,11 @@ __global__ __launch_bounds__(64 * MW) void fused_flood_kernel(const FusedArgs a)
 
 struct FusedPlan {
     bool eligible = false;
-    int32_t z = 0, layers = 0, N = 0, E = 0, M = 0;
+    int32_t z = 0, layers = 0, N = 0, E = 0, M = 0, max_deg = 0;
     int32_t *layer_ptr = nullptr, *ent_bc = nullptr, *ent_sh = nullptr, *layer_e0 = nullptr; /* device */
     int32_t *bcol_ptr = nullptr, *bcol_e0 = nullptr, *bcol_sh = nullptr;
+    int32_t *ent_pack = nullptr;
+    int32_t pack_w = 0;
     float *dump_p = nullptr, *dump_r = nullptr;
     uint8_t *conv = nullptr;
     int64_t dump_frames = 0;
@@ -300,7 +498,7 @@ struct FusedPlan {
 inline void fused_plan_destroy(FusedPlan *pl)
 {
     for (void *p : {(void *)pl->layer_ptr, (void *)pl->ent_bc, (void *)pl->ent_sh, (void *)pl->layer_e0,
-                    (void *)pl->bcol_ptr, (void *)pl->bcol_e0, (void *)pl->bcol_sh,
+                    (void *)pl->bcol_ptr, (void *)pl->bcol_e0, (void *)pl->bcol_sh, (void *)pl->ent_pack,
                     (void *)pl->dump_p, (void *)pl->dump_r, (void *)pl->conv})
         if (p) (void)hipFree(p);
     *pl = FusedPlan();
@@ -353,6 +551,8 @@ inline hipError_t fused_plan_create(FusedPlan *pl, int32_t M, int32_t N, int64_t
     if (z > 256 || (size_t)(N + E) * 4 > kFusedMaxLdsPerFrame) return hipSuccess;
     if (!fused_detect_qc(M, N, row_ptr, cols, z, lp, bc, sh, e0)) return hipSuccess;
     pl->z = z; pl->layers = M / z; pl->N = N; pl->E = (int32_t)E; pl->M = M;
+    pl->max_deg = 0;
+    for (size_t l = 0; l + 1 < lp.size(); ++l) pl->max_deg = std::max(pl->max_deg, lp[l + 1] - lp[l]);
     pl->lds_per_frame = (size_t)(N + E) * 4;
     auto up = [](int32_t **dst, const std::vector<int32_t> &v) {
         hipError_t e = hipMalloc((void **)dst, v.size() * sizeof(int32_t));
@@ -363,6 +563,17 @@ inline hipError_t fused_plan_create(FusedPlan *pl, int32_t M, int32_t N, int64_t
     if ((e = up(&pl->layer_ptr, lp)) || (e = up(&pl->ent_bc, bc)) || (e = up(&pl->ent_sh, sh)) ||
         (e = up(&pl->layer_e0, e0)))
         return e;
+    /* padded (block column << 16 | shift) rows, one wide scalar load per layer */
+    pl->pack_w = pl->max_deg <= 8 ? 8 : pl->max_deg <= 16 ? 16 : 24;
+    {
+        std::vector<int32_t> pk((size_t)(M / z) * pl->pack_w, 0);
+        for (int l = 0; l < M / z; ++l)
+            for (int k = 0; k < pl->pack_w; ++k) {
+                const int j = lp[l] + (k < lp[l + 1] - lp[l] ? k : 0);
+                pk[(size_t)l * pl->pack_w + k] = (bc[j] << 16) | sh[j];
+            }
+        if ((e = up(&pl->ent_pack, pk))) return e;
+    }
     /* column view: entries of every block column in ascending layer order */
     const int nb = N / z, layers = M / z;
     std::vector<int32_t> cp((size_t)nb + 1, 0), ce0, csh;
@@ -408,27 +619,42 @@ inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int
     }
     FusedArgs a{r.llr_dev, r.out_dev, r.iters_dev, r.summary, r.tap_iter ? pl->dump_p : nullptr,
                 r.tap_iter ? pl->dump_r : nullptr, nullptr, pl->layer_ptr, pl->ent_bc, pl->ent_sh,
-                pl->layer_e0, pl->bcol_ptr, pl->bcol_e0, pl->bcol_sh, r.frames, r.out_dev ? r.out_bytes : 0, pl->N, pl->E, r.K, pl->z, pl->layers,
+                pl->layer_e0, pl->ent_pack, pl->pack_w, pl->bcol_ptr, pl->bcol_e0, pl->bcol_sh, r.frames, r.out_dev ? r.out_bytes : 0, pl->N, pl->E, r.K, pl->z, pl->layers,
                 r.max_iter, rounds, r.early_term};
     const int mw = (pl->z + 63) / 64;
     const unsigned grid = (unsigned)r.frames;
-    if (r.flooding) {
-        switch (mw) {
-        case 1: fused_flood_kernel<1><<<grid, 64, pl->lds_per_frame, s>>>(a); break;
-        case 2: fused_flood_kernel<2><<<grid, 128, pl->lds_per_frame, s>>>(a); break;
-        case 3: fused_flood_kernel<3><<<grid, 192, pl->lds_per_frame, s>>>(a); break;
-        case 4: fused_flood_kernel<4><<<grid, 256, pl->lds_per_frame, s>>>(a); break;
-        default: return hipErrorInvalidValue;
-        }
-    } else {
-        switch (mw) {
-        case 1: fused_layered_kernel<1><<<grid, 64, pl->lds_per_frame, s>>>(a); break;
-        case 2: fused_layered_kernel<2><<<grid, 128, pl->lds_per_frame, s>>>(a); break;
-        case 3: fused_layered_kernel<3><<<grid, 192, pl->lds_per_frame, s>>>(a); break;
-        case 4: fused_layered_kernel<4><<<grid, 256, pl->lds_per_frame, s>>>(a); break;
-        default: return hipErrorInvalidValue;
-        }
+    /* DMAX: unrolled row width (8 / 16 / 24), 0 = run-time loops for anything wider */
+    const int dm = getenv("LDPC_TUNE_FUSED_LOOP") ? 0 : (pl->max_deg <= 8 ? 8 : pl->max_deg <= 16 ? 16 : pl->max_deg <= 24 ? 24 : 0);
+#define LDPC_FUSED_LAUNCH(KERNEL, MWV)                                                           \
+    do {                                                                                         \
+        if (dm == 8) KERNEL<MWV, 8><<<grid, 64 * MWV, pl->lds_per_frame, s>>>(a);                \
+        else if (dm == 16) KERNEL<MWV, 16><<<grid, 64 * MWV, pl->lds_per_frame, s>>>(a);         \
+        else if (dm == 24) KERNEL<MWV, 24><<<grid, 64 * MWV, pl->lds_per_frame, s>>>(a);         \
+        else KERNEL<MWV, 0><<<grid, 64 * MWV, pl->lds_per_frame, s>>>(a);                        \
+    } while (0)
+#define LDPC_FUSED_BY_MW(KERNEL)                                                                 \
+    switch (mw) {                                                                                \
+    case 1: LDPC_FUSED_LAUNCH(KERNEL, 1); break;                                                 \
+    case 2: LDPC_FUSED_LAUNCH(KERNEL, 2); break;                                                 \
+    case 3: LDPC_FUSED_LAUNCH(KERNEL, 3); break;                                                 \
+    case 4: LDPC_FUSED_LAUNCH(KERNEL, 4); break;                                                 \
+    default: return hipErrorInvalidValue;                                                        \
     }
+    if (r.flooding) {
+        LDPC_FUSED_BY_MW(fused_flood_kernel)
+    } else if (pl->z <= 32 && !getenv("LDPC_TUNE_NO_PACK")) {
+        const int G = 64 / pl->z;
+        const unsigned pgrid = (unsigned)((r.frames + G - 1) / G);
+        const size_t plds = G * pl->lds_per_frame;
+        if (dm == 8) fused_layered_packed_kernel<8><<<pgrid, 64, plds, s>>>(a, G);
+        else if (dm == 16) fused_layered_packed_kernel<16><<<pgrid, 64, plds, s>>>(a, G);
+        else if (dm == 24) fused_layered_packed_kernel<24><<<pgrid, 64, plds, s>>>(a, G);
+        else fused_layered_packed_kernel<0><<<pgrid, 64, plds, s>>>(a, G);
+    } else {
+        LDPC_FUSED_BY_MW(fused_layered_kernel)
+    }
+#undef LDPC_FUSED_BY_MW
+#undef LDPC_FUSED_LAUNCH
     *launched = rounds;
     return hipGetLastError();
 }
