@@ -138,7 +138,13 @@ __device__ __forceinline__ void fused_layer_row(float *P, float *Rl, const int32
 }
 
 /* Row parity of the hard decisions P < 0 (decodeCL.c:393-404), loads first as above. */
-template <int DMAX>
+/* hard decision: P < 0 (fused reference kernels, decodeCL.c:389,541) or !(P > 0) (MS chain, :161-165) */
+template <bool NOTPOS> __device__ __forceinline__ int fused_bit(float p)
+{
+    return NOTPOS ? (!(p > 0.0f) ? 1 : 0) : ((p < 0.0f) ? 1 : 0);
+}
+
+template <int DMAX, bool NOTPOS = false>
 __device__ __forceinline__ int fused_row_parity(const float *P, const int32_t *bc, const int32_t *sh,
                                                 const int32_t *pk, int d, int z, int r)
 {
@@ -147,7 +153,7 @@ __device__ __forceinline__ int fused_row_parity(const float *P, const int32_t *b
         for (int k = 0; k < d; ++k) {
             int t = r + sh[k];
             t = t >= z ? t - z : t;
-            par ^= (P[bc[k] * z + t] < 0.0f) ? 1 : 0;
+            par ^= fused_bit<NOTPOS>(P[bc[k] * z + t]);
         }
         return par;
     }
@@ -164,7 +170,7 @@ __device__ __forceinline__ int fused_row_parity(const float *P, const int32_t *b
     }
 #pragma unroll
     for (int k = 0; k < DM; ++k)
-        if (k < d) par ^= (v[k] < 0.0f) ? 1 : 0;
+        if (k < d) par ^= fused_bit<NOTPOS>(v[k]);
     return par;
 }
 
@@ -391,13 +397,78 @@ __device__ __forceinline__ void fused_flood_row(const float *P, float *Rl, const
         if (k < d) Rl[k * z + r] = cl_sign(q[k]) * ((k == bind) ? ac : ab);
 }
 
+/* Flooding row with the arithmetic of the MS kernel chain / decodeCPU (refreshRMS,
+ * decodeCL.c:126-147): sign = XOR of (q_j < 0) over the others, magnitude = fmin chain over the
+ * others' |q_j| from 1000 (two-smallest form, exact).  q_k = P[col_k] - R_k is refreshQMS
+ * (:185) applied on the fly. */
+template <int DMAX>
+__device__ __forceinline__ void fused_chain_row(const float *P, float *Rl, const int32_t *bc, const int32_t *sh,
+                                                const int32_t *pk, int d, int z, int r)
+{
+    if (DMAX == 0) {
+        float m1 = 1000.0f, m2 = 1000.0f;
+        int idx = -1;
+        unsigned par = 0;
+        for (int k = 0; k < d; ++k) {
+            int t = r + sh[k];
+            t = t >= z ? t - z : t;
+            const float q = P[bc[k] * z + t] - Rl[k * z + r];
+            Rl[k * z + r] = q;                                  /* parked for the second pass */
+            const float mag = __builtin_fabsf(q);
+            par ^= (q < 0.0f) ? 1u : 0u;
+            if (mag < m1) { m2 = m1; m1 = mag; idx = k; }
+            else if (mag < m2) { m2 = mag; }
+        }
+        for (int k = 0; k < d; ++k) {
+            const float q = Rl[k * z + r];
+            const float b = (k == idx) ? m2 : m1;
+            Rl[k * z + r] = (par ^ ((q < 0.0f) ? 1u : 0u)) ? -b : b;
+        }
+        return;
+    }
+    constexpr int DM = DMAX > 0 ? DMAX : 1;
+    float q[DM];
+    int ent[DM];
+#pragma unroll
+    for (int k = 0; k < DM; ++k) ent[k] = pk[k];
+#pragma unroll
+    for (int k = 0; k < DM; ++k) {
+        int t = r + (ent[k] & 0xffff);
+        t = t >= z ? t - z : t;
+        if (k < d) q[k] = P[(ent[k] >> 16) * z + t] - Rl[k * z + r];
+    }
+    float m1 = 1000.0f, m2 = 1000.0f;
+    int idx = -1;
+    unsigned par = 0;
+#pragma unroll
+    for (int k = 0; k < DM; ++k) {
+        if (k < d) {
+            const float mag = __builtin_fabsf(q[k]);
+            par ^= (q[k] < 0.0f) ? 1u : 0u;
+            if (mag < m1) { m2 = m1; m1 = mag; idx = k; }
+            else if (mag < m2) { m2 = mag; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < DM; ++k) {
+        if (k < d) {
+            const float b = (k == idx) ? m2 : m1;
+            Rl[k * z + r] = (par ^ ((q[k] < 0.0f) ? 1u : 0u)) ? -b : b;
+        }
+    }
+}
+
 /* Flooding counterpart: the reference's fused kernel decodeOnceMS (decodeCL.c:432-567,
  * DecodeMSCL).  Every iteration: all rows from the same posteriors (check node with the
  * product sign and the 1000/1001 two-minimum rule, :482-512), then every posterior rebuilt
  * as y + sum of its column's R in ascending row order (:515-531), bits = P < 0, syndrome.
  * Same LDS layout and lane mapping as fused_layered_kernel; y is re-read from global memory
  * (L2) instead of being kept in LDS. */
-template <int MW, int DMAX>
+/* CHAIN = false: decodeOnceMS arithmetic (DecodeMSCL).  CHAIN = true: the MS kernel chain's
+ * arithmetic (DecodeMS / DecodeCPU: XOR sign, fmin from 1000, bit = !(p > 0), decodeCL.c:126-186),
+ * so that short QC codes decode in one launch in those modes too, bit-identical to the
+ * streaming kernels. */
+template <int MW, int DMAX, bool CHAIN>
 __global__ __launch_bounds__(64 * MW) void fused_flood_kernel(const FusedArgs a)
 {
     extern __shared__ float lds[];
@@ -426,7 +497,10 @@ __global__ __launch_bounds__(64 * MW) void fused_flood_kernel(const FusedArgs a)
         if (r < z) {
             for (int l = 0; l < a.layers; ++l) {               /* rows never touch P here */
                 const int p0 = a.layer_ptr[l], d = a.layer_ptr[l + 1] - p0;
-                fused_flood_row<DMAX>(P, R + a.layer_e0[l], a.ent_bc + p0, a.ent_sh + p0, a.ent_pack + (size_t)l * a.pack_w, d, z, r);
+                if (CHAIN)
+                    fused_chain_row<DMAX>(P, R + a.layer_e0[l], a.ent_bc + p0, a.ent_sh + p0, a.ent_pack + (size_t)l * a.pack_w, d, z, r);
+                else
+                    fused_flood_row<DMAX>(P, R + a.layer_e0[l], a.ent_bc + p0, a.ent_sh + p0, a.ent_pack + (size_t)l * a.pack_w, d, z, r);
             }
         }
         sync();                                                /* :514 */
@@ -445,7 +519,7 @@ __global__ __launch_bounds__(64 * MW) void fused_flood_kernel(const FusedArgs a)
         if (r < z) {
             for (int l = 0; l < a.layers; ++l) {
                 const int p0 = a.layer_ptr[l], d = a.layer_ptr[l + 1] - p0;
-                bad |= fused_row_parity<DMAX>(P, a.ent_bc + p0, a.ent_sh + p0, a.ent_pack + (size_t)l * a.pack_w, d, z, r);
+                bad |= fused_row_parity<DMAX, CHAIN>(P, a.ent_bc + p0, a.ent_sh + p0, a.ent_pack + (size_t)l * a.pack_w, d, z, r);
             }
         }
         const int any_bad = (MW == 1) ? (__ballot(bad != 0) != 0ull) : __syncthreads_or(bad);
@@ -458,7 +532,7 @@ __global__ __launch_bounds__(64 * MW) void fused_flood_kernel(const FusedArgs a)
     for (int j = tid; j < a.K / 8; j += LANES) {                /* :561-569 */
         unsigned byte = 0;
 #pragma unroll
-        for (int bit = 0; bit < 8; ++bit) byte |= (P[j * 8 + bit] < 0.0f ? 1u : 0u) << bit;
+        for (int bit = 0; bit < 8; ++bit) byte |= (unsigned)fused_bit<CHAIN>(P[j * 8 + bit]) << bit;
         if (base + j < a.out_bytes) a.out[base + j] = (uint8_t)byte;
     }
     if (a.dump_p)
@@ -601,7 +675,7 @@ struct FusedRun {
     int32_t *iters_dev;
     int32_t K, max_iter, tap_iter, early_term;
     int32_t *summary;
-    int32_t flooding;   /* 0: layered (decodeOnceTDMP), 1: flooding (decodeOnceMS) */
+    int32_t flooding;   /* 0: layered (decodeOnceTDMP), 1: flooding (decodeOnceMS), 2: flooding with the MS chain's arithmetic */
 };
 
 inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int32_t *launched)
@@ -625,23 +699,26 @@ inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int
     const unsigned grid = (unsigned)r.frames;
     /* DMAX: unrolled row width (8 / 16 / 24), 0 = run-time loops for anything wider */
     const int dm = getenv("LDPC_TUNE_FUSED_LOOP") ? 0 : (pl->max_deg <= 8 ? 8 : pl->max_deg <= 16 ? 16 : pl->max_deg <= 24 ? 24 : 0);
-#define LDPC_FUSED_LAUNCH(KERNEL, MWV)                                                           \
+#define LDPC_FUSED_LAUNCH(KERNEL, MWV, ...)                                                      \
     do {                                                                                         \
-        if (dm == 8) KERNEL<MWV, 8><<<grid, 64 * MWV, pl->lds_per_frame, s>>>(a);                \
-        else if (dm == 16) KERNEL<MWV, 16><<<grid, 64 * MWV, pl->lds_per_frame, s>>>(a);         \
-        else if (dm == 24) KERNEL<MWV, 24><<<grid, 64 * MWV, pl->lds_per_frame, s>>>(a);         \
-        else KERNEL<MWV, 0><<<grid, 64 * MWV, pl->lds_per_frame, s>>>(a);                        \
+        if (dm == 8) KERNEL<MWV, 8 __VA_ARGS__><<<grid, 64 * MWV, pl->lds_per_frame, s>>>(a);    \
+        else if (dm == 16) KERNEL<MWV, 16 __VA_ARGS__><<<grid, 64 * MWV, pl->lds_per_frame, s>>>(a); \
+        else if (dm == 24) KERNEL<MWV, 24 __VA_ARGS__><<<grid, 64 * MWV, pl->lds_per_frame, s>>>(a); \
+        else KERNEL<MWV, 0 __VA_ARGS__><<<grid, 64 * MWV, pl->lds_per_frame, s>>>(a);            \
     } while (0)
-#define LDPC_FUSED_BY_MW(KERNEL)                                                                 \
+#define LDPC_FUSED_BY_MW(KERNEL, ...)                                                            \
     switch (mw) {                                                                                \
-    case 1: LDPC_FUSED_LAUNCH(KERNEL, 1); break;                                                 \
-    case 2: LDPC_FUSED_LAUNCH(KERNEL, 2); break;                                                 \
-    case 3: LDPC_FUSED_LAUNCH(KERNEL, 3); break;                                                 \
-    case 4: LDPC_FUSED_LAUNCH(KERNEL, 4); break;                                                 \
+    case 1: LDPC_FUSED_LAUNCH(KERNEL, 1, __VA_ARGS__); break;                                    \
+    case 2: LDPC_FUSED_LAUNCH(KERNEL, 2, __VA_ARGS__); break;                                    \
+    case 3: LDPC_FUSED_LAUNCH(KERNEL, 3, __VA_ARGS__); break;                                    \
+    case 4: LDPC_FUSED_LAUNCH(KERNEL, 4, __VA_ARGS__); break;                                    \
     default: return hipErrorInvalidValue;                                                        \
     }
-    if (r.flooding) {
-        LDPC_FUSED_BY_MW(fused_flood_kernel)
+#define LDPC_COMMA ,
+    if (r.flooding == 2) {
+        LDPC_FUSED_BY_MW(fused_flood_kernel, LDPC_COMMA true)
+    } else if (r.flooding) {
+        LDPC_FUSED_BY_MW(fused_flood_kernel, LDPC_COMMA false)
     } else if (pl->z <= 32 && !getenv("LDPC_TUNE_NO_PACK")) {
         const int G = 64 / pl->z;
         const unsigned pgrid = (unsigned)((r.frames + G - 1) / G);
@@ -651,8 +728,9 @@ inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int
         else if (dm == 24) fused_layered_packed_kernel<24><<<pgrid, 64, plds, s>>>(a, G);
         else fused_layered_packed_kernel<0><<<pgrid, 64, plds, s>>>(a, G);
     } else {
-        LDPC_FUSED_BY_MW(fused_layered_kernel)
+        LDPC_FUSED_BY_MW(fused_layered_kernel, )
     }
+#undef LDPC_COMMA
 #undef LDPC_FUSED_BY_MW
 #undef LDPC_FUSED_LAUNCH
     *launched = rounds;

@@ -674,39 +674,51 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
         if (rc) return fail(LDPC_ERR_HIP, "layered plan allocation failed: %s",
                             hipGetErrorString(hipGetLastError()));
     } else {
+        /* flooding min-sum on a short quasi-cyclic code (layer_rows = circulant size given): the
+         * same arithmetic in one LDS-resident launch (fused_flood_kernel<.., CHAIN>) */
+        if (cfg->algo == LDPC_ALGO_MS && cfg->msg_dtype == LDPC_MSG_F32 && cfg->layer_rows > 0 &&
+            cfg->frames_per_lane == 0 && (cfg->pack_mode == LDPC_PACK_BYTES || cfg->K % 8 == 0)) {
+            const char *fe = getenv("LDPC_TUNE_FUSED");
+            if (!(fe && atoi(fe) == 0)) {
+                HIP_TRY(ldpc::fused_plan_create(&d->fused, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows));
+                d->use_fused = d->fused.eligible;
+            }
+        }
+        if (!d->use_fused) {
         d->msg_size = cfg->msg_dtype == LDPC_MSG_F16 ? 2 : 4;
-        HIP_TRY(d->chan.alloc(TF * d->N * d->msg_size));
-        HIP_TRY(d->Q.alloc(TF * (size_t)d->E * d->msg_size));
-        HIP_TRY(d->R.alloc(TF * (size_t)d->E * d->msg_size));
-        int rc = build_classes(d, g);
-        if (rc) return rc;
-        constexpr int DM = ldpc::kMaxUnrolledDegree;
-        using ldpc::kAlgoMS;
-        using ldpc::kAlgoSP;
-        using ldpc::hf;
-#define LDPC_FILL(ALGO, TYPE)                                                                          \
-    do {                                                                                               \
-        if (d->V == 1) FloodTable<ALGO, 1, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);  \
-        else if (d->V == 2) FloodTable<ALGO, 2, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn); \
-        else FloodTable<ALGO, 4, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);            \
-        d->init_fn = pick_init<ALGO, TYPE>(d->V);                                                      \
-        if (d->V == 1) LinkTable<ALGO, 1, TYPE, DM>::fill(d->link_fn);                                 \
-        else if (d->V == 2) LinkTable<ALGO, 2, TYPE, DM>::fill(d->link_fn);                            \
-        else LinkTable<ALGO, 4, TYPE, DM>::fill(d->link_fn);                                           \
-    } while (0)
-#define LDPC_FILL_MS_HIGH(TYPE)                                                                         \
-    do {                                                                                               \
-        constexpr int DH = ldpc::kMaxUnrolledCheckDegreeMS;                                            \
-        if (d->V == 1) CheckTableMS<1, TYPE, DH>::fill(d->check_fn, d->check_fn_wide);                 \
-        else if (d->V == 2) CheckTableMS<2, TYPE, DH>::fill(d->check_fn, d->check_fn_wide);            \
-        else CheckTableMS<4, TYPE, DH>::fill(d->check_fn, d->check_fn_wide);                           \
-        d->max_check_unrolled = DH;                                                                    \
-    } while (0)
-        if (cfg->algo == LDPC_ALGO_SP) LDPC_FILL(kAlgoSP, float);
-        else if (cfg->msg_dtype == LDPC_MSG_F16) { LDPC_FILL(kAlgoMS, hf); LDPC_FILL_MS_HIGH(hf); }
-        else { LDPC_FILL(kAlgoMS, float); LDPC_FILL_MS_HIGH(float); }
-#undef LDPC_FILL
-#undef LDPC_FILL_MS_HIGH
+            HIP_TRY(d->chan.alloc(TF * d->N * d->msg_size));
+            HIP_TRY(d->Q.alloc(TF * (size_t)d->E * d->msg_size));
+            HIP_TRY(d->R.alloc(TF * (size_t)d->E * d->msg_size));
+            int rc = build_classes(d, g);
+            if (rc) return rc;
+            constexpr int DM = ldpc::kMaxUnrolledDegree;
+            using ldpc::kAlgoMS;
+            using ldpc::kAlgoSP;
+            using ldpc::hf;
+    #define LDPC_FILL(ALGO, TYPE)                                                                          \
+        do {                                                                                               \
+            if (d->V == 1) FloodTable<ALGO, 1, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);  \
+            else if (d->V == 2) FloodTable<ALGO, 2, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn); \
+            else FloodTable<ALGO, 4, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);            \
+            d->init_fn = pick_init<ALGO, TYPE>(d->V);                                                      \
+            if (d->V == 1) LinkTable<ALGO, 1, TYPE, DM>::fill(d->link_fn);                                 \
+            else if (d->V == 2) LinkTable<ALGO, 2, TYPE, DM>::fill(d->link_fn);                            \
+            else LinkTable<ALGO, 4, TYPE, DM>::fill(d->link_fn);                                           \
+        } while (0)
+    #define LDPC_FILL_MS_HIGH(TYPE)                                                                         \
+        do {                                                                                               \
+            constexpr int DH = ldpc::kMaxUnrolledCheckDegreeMS;                                            \
+            if (d->V == 1) CheckTableMS<1, TYPE, DH>::fill(d->check_fn, d->check_fn_wide);                 \
+            else if (d->V == 2) CheckTableMS<2, TYPE, DH>::fill(d->check_fn, d->check_fn_wide);            \
+            else CheckTableMS<4, TYPE, DH>::fill(d->check_fn, d->check_fn_wide);                           \
+            d->max_check_unrolled = DH;                                                                    \
+        } while (0)
+            if (cfg->algo == LDPC_ALGO_SP) LDPC_FILL(kAlgoSP, float);
+            else if (cfg->msg_dtype == LDPC_MSG_F16) { LDPC_FILL(kAlgoMS, hf); LDPC_FILL_MS_HIGH(hf); }
+            else { LDPC_FILL(kAlgoMS, float); LDPC_FILL_MS_HIGH(float); }
+    #undef LDPC_FILL
+    #undef LDPC_FILL_MS_HIGH
+    }
     }
     *out = guard.release();
     return LDPC_OK;
@@ -746,7 +758,7 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
     if (d->use_fused) {
         ldpc::FusedRun run{llr_dev, frames, out_dev, std::min(out_bytes, need), iters_dev, d->cfg.K,
                            d->cfg.max_iter, d->tap_iter, d->cfg.early_term, d->summary.p,
-                           d->cfg.algo == LDPC_ALGO_MS_FUSED ? 1 : 0};
+                           d->cfg.algo == LDPC_ALGO_MS_FUSED ? 1 : (d->cfg.algo == LDPC_ALGO_MS ? 2 : 0)};
         hipError_t e = span_begin(d, s, 2, 0, (int64_t)frames * (4 * d->N + d->cfg.K / 8));
         if (e == hipSuccess) e = ldpc::fused_run(&d->fused, run, s, &d->last_iterations);
         if (e == hipSuccess) e = span_end(d, s);

@@ -141,6 +141,32 @@ def test_layered_streaming_and_fused_paths_agree(built, monkeypatch):
             dec.close()
 
 
+def test_min_sum_fused_and_streaming_paths_agree(built, monkeypatch):
+    """DecodeMS / DecodeCPU on short QC codes (circulant size given as layer_rows) run the MS
+    chain's arithmetic in one LDS-resident launch; LDPC_TUNE_FUSED=0 keeps the streaming
+    kernels.  Both must equal the oracle (bytes, iteration counts, messages)."""
+    for rate, N, sigma, B in ((4, 576, 0.55, 70), (0, 648, 0.8, 9), (3, 1152, 0.6, 9), (0, 2304, 0.9, 6), (5, 960, 0.45, 40)):
+        g, og, K, M, z = _graph(rate, N)
+        y = channel.awgn_frames(N, 0, B, sigma, seed=15)
+        want = oracle.decode(og, y, "ms", tap_iter=2)
+        for fused in ("1", "0"):
+            monkeypatch.setenv("LDPC_TUNE_FUSED", fused)
+            dec = L.Decoder(g, K, max_batch=B, algo="ms", layer_rows=z)
+            out, iters = dec.decode(y)
+            assert np.array_equal(out, want["out"]) and np.array_equal(iters, want["iters"]), (rate, N, fused)
+            assert dec.stats()["batch_time"] == int(want["iters"].max())
+            dec.set_tap(2)
+            dec.decode(y)
+            run = np.nonzero(want["iters"] >= 2)[0]
+            assert np.array_equal(dec.dump(0, B)[run], want["taps"]["r"][run]), fused
+            dec.close()
+        if K % 8 == 0:
+            dec = L.Decoder(g, K, max_batch=B, algo="ms", layer_rows=z, pack_mode=L.PACK_BITS)   # DecodeCPU
+            out, iters = dec.decode(y)
+            assert np.array_equal(out, oracle.decode(og, y, "ms", pack_mode=1)["out"])
+            dec.close()
+
+
 @pytest.mark.parametrize("algo", ["ms", "sp", "layered"])
 def test_ragged_batches_and_chunking(built, algo):
     """frames not a multiple of the tile, more frames than max_batch (Coder::decode's
