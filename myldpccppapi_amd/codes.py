@@ -246,3 +246,56 @@ def nr_bg1_profile_encode(base, Z, info_bits):
     for r in range(4, 46):
         cw[(26 + r - 4) * Z:(27 + r - 4) * Z] = lam(r, 26)
     return cw
+
+
+# ----------------------------------------------------------------------------- alist
+
+def load_alist(path):
+    """Read a parity-check matrix in MacKay's alist format (the usual interchange format
+    for LDPC matrices) and return (rows, cols, M, N) in row-major edge order.
+
+    Layout: "N M", "max_col_deg max_row_deg", N column degrees, M row degrees, then N lines of
+    1-based row indices per column (0-padded) and M lines of 1-based column indices per row.
+    Only the per-column lists are used; the per-row lists are checked against them."""
+    tok = open(path).read().split()
+    it = iter(int(t) for t in tok)
+    N, M = next(it), next(it)
+    next(it), next(it)
+    cdeg = [next(it) for _ in range(N)]
+    rdeg = [next(it) for _ in range(M)]
+    maxc, maxr = max(cdeg), max(rdeg)
+    rows, cols = [], []
+    rest = list(it)
+    pos = 0
+    # each column line holds either exactly deg entries or max_col_deg entries (0-padded)
+    padded = len(rest) >= N * maxc + M * maxr
+    for c in range(N):
+        w = maxc if padded else cdeg[c]
+        ent = [r for r in rest[pos:pos + w] if r > 0]
+        pos += w
+        if len(ent) != cdeg[c]:
+            raise ValueError("alist: column %d lists %d rows, header says %d" % (c, len(ent), cdeg[c]))
+        rows += [r - 1 for r in ent]
+        cols += [c] * len(ent)
+    rr, cc = row_major(rows, cols)
+    if not np.array_equal(np.bincount(rr, minlength=M), np.array(rdeg)):
+        raise ValueError("alist: row degrees do not match the column lists")
+    return rr, cc, M, N
+
+
+def save_alist(path, rows, cols, M, N):
+    """Write an edge list as alist (0-padded lines)."""
+    rows, cols = np.asarray(rows), np.asarray(cols)
+    cdeg, rdeg = np.bincount(cols, minlength=N), np.bincount(rows, minlength=M)
+    by_col = [[] for _ in range(N)]
+    by_row = [[] for _ in range(M)]
+    for r, c in zip(rows.tolist(), cols.tolist()):
+        by_col[c].append(r + 1)
+        by_row[r].append(c + 1)
+    with open(path, "w") as f:
+        f.write("%d %d\n%d %d\n" % (N, M, cdeg.max(), rdeg.max()))
+        f.write(" ".join(map(str, cdeg)) + "\n" + " ".join(map(str, rdeg)) + "\n")
+        for c in range(N):
+            f.write(" ".join(map(str, sorted(by_col[c]) + [0] * (cdeg.max() - cdeg[c]))) + "\n")
+        for r in range(M):
+            f.write(" ".join(map(str, sorted(by_row[r]) + [0] * (rdeg.max() - rdeg[r]))) + "\n")

@@ -382,3 +382,13 @@ def test_cpp_coder_round_trip_like_test_cpp(built, tmp_path):
         assert "ParityFail=0" in out.stdout and "ErrNum=0" in out.stdout, out.stdout
     out = subprocess.run([exe, "0", "2304", "5000", "16", "3.5", "SP"], capture_output=True, text=True)
     assert "ErrNum=0" in out.stdout, out.stdout
+    # MyTest: the reference's CLI itself (same argv and printed fields, Test.cpp:16,35,48,56,61-112)
+    mytest = os.path.join(ROOT, "myldpccppapi_amd", "MyTest")
+    for mode in ("SP", "MS", "CPU", "TDMP", "TDMPCL", "MSCL"):
+        out = subprocess.run([mytest, "20000", "128", "6", mode], capture_output=True, text=True,
+                             env=dict(os.environ, MYTEST_SEED="5"))
+        assert out.returncode == 0, out.stdout + out.stderr
+        fields = dict(l.split("=", 1) for l in out.stdout.split() if "=" in l)
+        assert fields["ErrNum"] == "0" and float(fields["ThroughPut"]) > 0 and "sd" in fields and "Time" in fields
+        assert any(l.startswith(mode + ":") for l in out.stdout.split())
+    assert subprocess.run([mytest, "1"], capture_output=True).returncode == 2

@@ -115,6 +115,15 @@ def test_bg1_profile_layers_are_column_disjoint():
         assert len(np.unique(cs)) == len(cs)
 
 
+def test_alist_round_trip(tmp_path):
+    rows, cols = codes.wimax_edges(codes.RATE_2_3_A, 672)
+    K, M, z = codes.wimax_dims(codes.RATE_2_3_A, 672)
+    p = str(tmp_path / "h.alist")
+    codes.save_alist(p, rows, cols, M, 672)
+    r2, c2, M2, N2 = codes.load_alist(p)
+    assert (M2, N2) == (M, 672) and np.array_equal(r2, rows) and np.array_equal(c2, cols)
+
+
 def test_channel_is_counter_based():
     a = channel.awgn_frames(648, 0, 6, 0.8, seed=5)
     b = channel.awgn_frames(648, 4, 2, 0.8, seed=5)

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""BER / FER versus SNR on the GPU, in the reference's convention (Test.cpp:56-57):
+BPSK +-1, sd = 10^(-SNR_dB/20), all-zero codeword (valid for every linear code), noise generated
+in HBM (torch.randn, seeded).  The reference counts differing BYTES (Test.cpp:105-110); this
+prints byte errors too.
+
+    python tools/ber_sweep.py [--code dvbs2_12|dvbs2_910|bg1|wimax:<rate>:<N>] [--algo sp|ms|layered]
+                              [--snr 1.0,1.5,...] [--frames 4096] [--iters 50]
+The DVB-S2 / BG1 codes are PROFILE SURROGATES (codes.py): the numbers are not the standards'."""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import torch
+import myldpccppapi_amd as L
+from myldpccppapi_amd import codes
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--code", default="dvbs2_12")
+ap.add_argument("--algo", default="sp")
+ap.add_argument("--snr", default="2.5,3.0,3.5,4.0,4.5,5.0")
+ap.add_argument("--frames", type=int, default=4096)
+ap.add_argument("--iters", type=int, default=50)
+ap.add_argument("--llr-scale", type=float, default=8.0)
+args = ap.parse_args()
+
+layer = 0
+if args.code == "dvbs2_12":
+    N, K = 64800, 32400
+    rows, cols = codes.dvbs2_profile_edges(N, K)
+elif args.code == "dvbs2_910":
+    N, K = 64800, 58320
+    rows, cols = codes.dvbs2_profile_edges(N, K)
+elif args.code == "bg1":
+    Z = 384
+    N, K, layer = 68 * Z, 22 * Z, Z
+    rows, cols = codes.nr_bg1_profile_edges(Z)
+else:
+    _, rate, N = args.code.split(":")
+    rate, N = int(rate), int(N)
+    K, M, layer = codes.wimax_dims(rate, N)
+    rows, cols = codes.wimax_edges(rate, N)
+M = N - K
+g = L.Graph(rows, cols, M, N)
+B = args.frames
+dec = L.Decoder(g, K, max_batch=B, algo=args.algo, max_iter=args.iters, llr_scale=args.llr_scale,
+                layer_rows=layer, poll_interval=2)
+out = torch.empty(L.out_bytes(K, B), dtype=torch.uint8, device="cuda")
+it = torch.empty(B, dtype=torch.int32, device="cuda")
+popc = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device="cuda")
+gen = torch.Generator(device="cuda")
+gen.manual_seed(20260101)
+print("code=%s algo=%s frames=%d max_iter=%d (info bits per point: %d)" % (args.code, args.algo, B, args.iters, B * K))
+for snr in [float(x) for x in args.snr.split(",")]:
+    sd = 10.0 ** (-snr / 20.0)
+    y = 1.0 + sd * torch.randn(B, N, device="cuda", dtype=torch.float32, generator=gen)
+    dec.decode_device(y.data_ptr(), B, out.data_ptr(), out.numel(), it.data_ptr(), None)
+    torch.cuda.synchronize()
+    o = out.view(B, K // 8)
+    bit_err = int(popc[o.long()].sum())
+    byte_err = int((o != 0).sum())
+    frame_err = int((o != 0).any(dim=1).sum())
+    print(json.dumps({"snr_db": snr, "sd": round(sd, 4), "ber": bit_err / (B * K), "bit_errors": bit_err,
+                      "byte_errors": byte_err, "fer": frame_err / B, "avg_iters": round(float(it.float().mean()), 2),
+                      "frames_converged": dec.stats()["frames_converged"]}))
