@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "layered_kernels.hpp"
+#include "ldpc_expf.h"
 
 namespace ldpc {
 
@@ -45,6 +46,9 @@ struct FusedArgs {
     float *__restrict__ dump_p;           /* [frames][N] or nullptr (taps) */
     float *__restrict__ dump_r;           /* [frames][E] reference edge order, or nullptr */
     uint8_t *__restrict__ conv;           /* [frames] 1 = syndrome clean, or nullptr */
+    float *__restrict__ dump_q;           /* sum-product taps: [frames][E] q0-q1 */
+    uint8_t *__restrict__ dump_b;         /* sum-product taps: [frames][N] hard bits */
+    float llr_scale;                      /* sum-product: exp(llr_scale * y), decodeCL.c:9 */
     const int32_t *__restrict__ layer_ptr;/* [layers+1] into the entry tables */
     const int32_t *__restrict__ ent_bc;   /* block column of entry */
     const int32_t *__restrict__ ent_sh;   /* circulant shift of entry */
@@ -554,6 +558,164 @@ __global__ __launch_bounds__(64 * MW) void fused_flood_kernel(const FusedArgs a)
     }
 }
 
+/* Sum-product in the probability domain (decodeCL.c:3-108: decodeInit, refreshR, hardDecision,
+ * checkResult, refreshQ), whole decode in LDS for short QC codes -- same stored quantities and
+ * the same fp32 operation order as check_kernel<SP> / var_kernel<SP>: Q = q0-q1 and R = r0-r1
+ * per edge, T = exp(scale*y) per column, products left to right in ascending edge id with the
+ * own edge skipped, IEEE divides, ties and NaN keep the previous hard bit.
+ * LDS per frame: T[N] + Q[E] + R[E] floats + N bit bytes.  Rows: lanes = the z rows of a layer
+ * (as in the other fused kernels).  Columns: lanes = consecutive columns; a column of block
+ * column bc at offset t meets, for its j-th entry (layer, k, shift), row (t - shift) mod z. */
+template <int MW, int DMAX, int DVMAX>
+__global__ __launch_bounds__(64 * MW) void fused_sp_kernel(const FusedArgs a)
+{
+    extern __shared__ float lds[];
+    const int tid = (int)threadIdx.x;
+    const int64_t frame = (int64_t)blockIdx.x;
+    float *T = lds;
+    float *Q = T + a.N;
+    float *R = Q + a.E;
+    uint8_t *bits = reinterpret_cast<uint8_t *>(R + a.E);
+    constexpr int LANES = 64 * MW;
+    const int z = a.z;
+    const int r = tid;
+    auto sync = [&]() {
+        if (MW == 1) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __syncthreads();
+        }
+    };
+    /* decodeInit, decodeCL.c:3-22 */
+    const float *y = a.llr + (size_t)frame * a.N;
+    for (int n = tid; n < a.N; n += LANES) {
+        const int bc = n / z, t = n - bc * z;
+        const float e = ldpc_expf(a.llr_scale * y[n]);
+        T[n] = e;
+        bits[n] = 0;
+        const float q = e / (1.0f + e) - 1.0f / (1.0f + e);
+        for (int j = a.bcol_ptr[bc]; j < a.bcol_ptr[bc + 1]; ++j) {
+            int rr = t - a.bcol_sh[j];
+            rr = rr < 0 ? rr + z : rr;
+            Q[a.bcol_e0[j] + rr] = q;
+        }
+    }
+    sync();
+    int time = 0;
+    bool clean = false;
+    while (true) {
+        /* refreshR, decodeCL.c:25-41 */
+        if (r < z) {
+            for (int l = 0; l < a.layers; ++l) {
+                const int d = a.layer_ptr[l + 1] - a.layer_ptr[l];
+                const int e0 = a.layer_e0[l];
+                float x[DMAX];
+#pragma unroll
+                for (int k = 0; k < DMAX; ++k)
+                    if (k < d) x[k] = Q[e0 + k * z + r];
+                float pre = 1.0f;                  /* 1.0f * x is exact: the chain starts at the first factor */
+#pragma unroll
+                for (int k = 0; k < DMAX; ++k) {
+                    if (k < d) {
+                        float p = pre;
+#pragma unroll
+                        for (int j = k + 1; j < DMAX; ++j)
+                            if (j < d) p *= x[j];
+                        R[e0 + k * z + r] = p;
+                        pre *= x[k];
+                    }
+                }
+            }
+        }
+        sync();
+        /* hardDecision (:64-86) + refreshQ (:43-62), shared prefix products */
+        for (int n = tid; n < a.N; n += LANES) {
+            const int bc = n / z, t = n - bc * z;
+            const int jb = a.bcol_ptr[bc], dv = a.bcol_ptr[bc + 1] - jb;
+            int slot[DVMAX];
+            float r0[DVMAX], r1[DVMAX];
+#pragma unroll
+            for (int j = 0; j < DVMAX; ++j) {
+                if (j < dv) {
+                    int rr = t - a.bcol_sh[jb + j];
+                    rr = rr < 0 ? rr + z : rr;
+                    slot[j] = a.bcol_e0[jb + j] + rr;
+                    const float dj = R[slot[j]];
+                    r0[j] = (1.0f + dj) * 0.5f;
+                    r1[j] = (1.0f - dj) * 0.5f;
+                }
+            }
+            const float den = 1.0f + T[n];
+            float pre0 = T[n] / den, pre1 = 1.0f / den;
+#pragma unroll
+            for (int k = 0; k < DVMAX; ++k) {
+                if (k < dv) {
+                    float t0 = pre0, t1 = pre1;
+#pragma unroll
+                    for (int j = k + 1; j < DVMAX; ++j)
+                        if (j < dv) { t0 *= r0[j]; t1 *= r1[j]; }
+                    const float ssum = t0 + t1;
+                    Q[slot[k]] = t0 / ssum - t1 / ssum;
+                    pre0 *= r0[k];
+                    pre1 *= r1[k];
+                }
+            }
+            if (pre0 > pre1) bits[n] = 0;
+            else if (pre0 < pre1) bits[n] = 1;          /* ties / NaN: unchanged, :78-82 */
+        }
+        sync();
+        /* checkResult, :88-108 */
+        int bad = 0;
+        if (r < z) {
+            for (int l = 0; l < a.layers; ++l) {
+                const int p0 = a.layer_ptr[l], d = a.layer_ptr[l + 1] - p0;
+                const int32_t *pk = a.ent_pack + (size_t)l * a.pack_w;
+                int par = 0;
+                for (int k = 0; k < d; ++k) {
+                    int t = r + (pk[k] & 0xffff);
+                    t = t >= z ? t - z : t;
+                    par ^= bits[(pk[k] >> 16) * z + t];
+                }
+                bad |= par;
+            }
+        }
+        const int any_bad = (MW == 1) ? (__ballot(bad != 0) != 0ull) : __syncthreads_or(bad);
+        ++time;
+        clean = !any_bad;
+        if ((clean && a.early_term) || time == a.rounds) break;    /* MyLdpc.cpp:1031-1039 */
+    }
+    sync();
+    const int64_t base = frame * (int64_t)a.K / 8;
+    for (int j = tid; j < a.K / 8; j += LANES) {                    /* toChar, :188-199 */
+        unsigned byte = 0;
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) byte |= (unsigned)bits[j * 8 + bit] << bit;
+        if (base + j < a.out_bytes) a.out[base + j] = (uint8_t)byte;
+    }
+    if (a.dump_p)
+        for (int n = tid; n < a.N; n += LANES) {
+            a.dump_p[(size_t)frame * a.N + n] = T[n];
+            a.dump_b[(size_t)frame * a.N + n] = bits[n];
+        }
+    if (a.dump_r) {
+        for (int l = 0; l < a.layers; ++l) {
+            const int d = a.layer_ptr[l + 1] - a.layer_ptr[l], e0 = a.layer_e0[l];
+            for (int i = tid; i < d * z; i += LANES) {
+                const int rr = i / d, k = i % d;
+                a.dump_r[(size_t)frame * a.E + e0 + i] = R[e0 + k * z + rr];
+                a.dump_q[(size_t)frame * a.E + e0 + i] = Q[e0 + k * z + rr];
+            }
+        }
+    }
+    if (tid == 0) {
+        const int it = clean ? time : a.max_iter;
+        if (a.iters) a.iters[frame] = it;
+        atomicMax(&a.summary[0], it);
+        if (clean) atomicAdd(&a.summary[1], 1);
+    }
+}
+
 /* ---------------------------------------------------------------- host side */
 
 struct FusedPlan {
@@ -563,8 +725,11 @@ struct FusedPlan {
     int32_t *bcol_ptr = nullptr, *bcol_e0 = nullptr, *bcol_sh = nullptr;
     int32_t *ent_pack = nullptr;
     int32_t pack_w = 0;
-    float *dump_p = nullptr, *dump_r = nullptr;
-    uint8_t *conv = nullptr;
+    float *dump_p = nullptr, *dump_r = nullptr, *dump_q = nullptr;
+    uint8_t *conv = nullptr, *dump_b = nullptr;
+    int32_t max_col_deg = 0;
+    bool eligible_sp = false;
+    size_t lds_sp = 0;
     int64_t dump_frames = 0;
     size_t lds_per_frame = 0;
 };
@@ -573,7 +738,7 @@ inline void fused_plan_destroy(FusedPlan *pl)
 {
     for (void *p : {(void *)pl->layer_ptr, (void *)pl->ent_bc, (void *)pl->ent_sh, (void *)pl->layer_e0,
                     (void *)pl->bcol_ptr, (void *)pl->bcol_e0, (void *)pl->bcol_sh, (void *)pl->ent_pack,
-                    (void *)pl->dump_p, (void *)pl->dump_r, (void *)pl->conv})
+                    (void *)pl->dump_p, (void *)pl->dump_r, (void *)pl->conv, (void *)pl->dump_q, (void *)pl->dump_b})
         if (p) (void)hipFree(p);
     *pl = FusedPlan();
 }
@@ -663,6 +828,10 @@ inline hipError_t fused_plan_create(FusedPlan *pl, int32_t M, int32_t N, int64_t
             csh[slot] = sh[j];
         }
     if ((e = up(&pl->bcol_ptr, cp)) || (e = up(&pl->bcol_e0, ce0)) || (e = up(&pl->bcol_sh, csh))) return e;
+    pl->max_col_deg = 0;
+    for (int b = 0; b < nb; ++b) pl->max_col_deg = std::max(pl->max_col_deg, cp[b + 1] - cp[b]);
+    pl->lds_sp = (size_t)(N + 2 * E) * 4 + (((size_t)N + 3) & ~(size_t)3);
+    pl->eligible_sp = pl->max_deg <= 24 && pl->max_col_deg <= 8 && pl->lds_sp <= kFusedMaxLdsPerFrame;
     pl->eligible = true;
     return hipSuccess;
 }
@@ -675,7 +844,9 @@ struct FusedRun {
     int32_t *iters_dev;
     int32_t K, max_iter, tap_iter, early_term;
     int32_t *summary;
-    int32_t flooding;   /* 0: layered (decodeOnceTDMP), 1: flooding (decodeOnceMS), 2: flooding with the MS chain's arithmetic */
+    int32_t flooding;   /* 0: layered (decodeOnceTDMP), 1: flooding (decodeOnceMS), 2: flooding with the MS chain's
+                           arithmetic, 3: sum-product */
+    float llr_scale;
 };
 
 inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int32_t *launched)
@@ -684,15 +855,19 @@ inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int
     if ((e = hipMemsetAsync(r.summary, 0, 2 * sizeof(int32_t), s))) return e;
     const int rounds = r.tap_iter ? (r.tap_iter < r.max_iter ? r.tap_iter : r.max_iter) : r.max_iter;
     if (r.tap_iter && pl->dump_frames < r.frames) {
-        if (pl->dump_p) (void)hipFree(pl->dump_p);
-        if (pl->dump_r) (void)hipFree(pl->dump_r);
-        pl->dump_p = pl->dump_r = nullptr;
+        for (void *p : {(void *)pl->dump_p, (void *)pl->dump_r, (void *)pl->dump_q, (void *)pl->dump_b})
+            if (p) (void)hipFree(p);
+        pl->dump_p = pl->dump_r = pl->dump_q = nullptr;
+        pl->dump_b = nullptr;
         if ((e = hipMalloc((void **)&pl->dump_p, (size_t)r.frames * pl->N * sizeof(float)))) return e;
         if ((e = hipMalloc((void **)&pl->dump_r, (size_t)r.frames * pl->E * sizeof(float)))) return e;
+        if ((e = hipMalloc((void **)&pl->dump_q, (size_t)r.frames * pl->E * sizeof(float)))) return e;
+        if ((e = hipMalloc((void **)&pl->dump_b, (size_t)r.frames * pl->N))) return e;
         pl->dump_frames = r.frames;
     }
     FusedArgs a{r.llr_dev, r.out_dev, r.iters_dev, r.summary, r.tap_iter ? pl->dump_p : nullptr,
-                r.tap_iter ? pl->dump_r : nullptr, nullptr, pl->layer_ptr, pl->ent_bc, pl->ent_sh,
+                r.tap_iter ? pl->dump_r : nullptr, nullptr, r.tap_iter ? pl->dump_q : nullptr,
+                r.tap_iter ? pl->dump_b : nullptr, r.llr_scale, pl->layer_ptr, pl->ent_bc, pl->ent_sh,
                 pl->layer_e0, pl->ent_pack, pl->pack_w, pl->bcol_ptr, pl->bcol_e0, pl->bcol_sh, r.frames, r.out_dev ? r.out_bytes : 0, pl->N, pl->E, r.K, pl->z, pl->layers,
                 r.max_iter, rounds, r.early_term};
     const int mw = (pl->z + 63) / 64;
@@ -715,7 +890,17 @@ inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int
     default: return hipErrorInvalidValue;                                                        \
     }
 #define LDPC_COMMA ,
-    if (r.flooding == 2) {
+    if (r.flooding == 3) {
+        switch (mw * 100 + dm) {
+#define LDPC_SP_CASE(MWV, DMV) case MWV * 100 + DMV: fused_sp_kernel<MWV, DMV, 8><<<grid, 64 * MWV, pl->lds_sp, s>>>(a); break
+            LDPC_SP_CASE(1, 8); LDPC_SP_CASE(1, 16); LDPC_SP_CASE(1, 24);
+            LDPC_SP_CASE(2, 8); LDPC_SP_CASE(2, 16); LDPC_SP_CASE(2, 24);
+            LDPC_SP_CASE(3, 8); LDPC_SP_CASE(3, 16); LDPC_SP_CASE(3, 24);
+            LDPC_SP_CASE(4, 8); LDPC_SP_CASE(4, 16); LDPC_SP_CASE(4, 24);
+#undef LDPC_SP_CASE
+        default: return hipErrorInvalidValue;
+        }
+    } else if (r.flooding == 2) {
         LDPC_FUSED_BY_MW(fused_flood_kernel, LDPC_COMMA true)
     } else if (r.flooding) {
         LDPC_FUSED_BY_MW(fused_flood_kernel, LDPC_COMMA false)

@@ -676,12 +676,17 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     } else {
         /* flooding min-sum on a short quasi-cyclic code (layer_rows = circulant size given): the
          * same arithmetic in one LDS-resident launch (fused_flood_kernel<.., CHAIN>) */
-        if (cfg->algo == LDPC_ALGO_MS && cfg->msg_dtype == LDPC_MSG_F32 && cfg->layer_rows > 0 &&
-            cfg->frames_per_lane == 0 && (cfg->pack_mode == LDPC_PACK_BYTES || cfg->K % 8 == 0)) {
+        /* Measured (tools/gpu_short.py): for the flooding schedules the streaming kernels win at
+         * full work once the batch is large (HBM-bound, 1.3-1.9x), the fused kernels win on latency
+         * and for small batches; crossover near max_batch * E = 2^23 edge-frames.
+         * LDPC_TUNE_FUSED=1 forces the fused kernels, =0 the streaming ones. */
+        if (cfg->msg_dtype == LDPC_MSG_F32 && cfg->layer_rows > 0 && cfg->frames_per_lane == 0 &&
+            (cfg->pack_mode == LDPC_PACK_BYTES || cfg->K % 8 == 0)) {
             const char *fe = getenv("LDPC_TUNE_FUSED");
-            if (!(fe && atoi(fe) == 0)) {
+            const bool small = (int64_t)cfg->max_batch * g->E <= (int64_t)1 << 23;
+            if (fe ? atoi(fe) != 0 : small) {
                 HIP_TRY(ldpc::fused_plan_create(&d->fused, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows));
-                d->use_fused = d->fused.eligible;
+                d->use_fused = d->fused.eligible && (cfg->algo == LDPC_ALGO_MS || d->fused.eligible_sp);
             }
         }
         if (!d->use_fused) {
@@ -758,7 +763,8 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
     if (d->use_fused) {
         ldpc::FusedRun run{llr_dev, frames, out_dev, std::min(out_bytes, need), iters_dev, d->cfg.K,
                            d->cfg.max_iter, d->tap_iter, d->cfg.early_term, d->summary.p,
-                           d->cfg.algo == LDPC_ALGO_MS_FUSED ? 1 : (d->cfg.algo == LDPC_ALGO_MS ? 2 : 0)};
+                           d->cfg.algo == LDPC_ALGO_MS_FUSED ? 1 : (d->cfg.algo == LDPC_ALGO_MS ? 2 : (d->cfg.algo == LDPC_ALGO_SP ? 3 : 0)),
+                           d->cfg.llr_scale};
         hipError_t e = span_begin(d, s, 2, 0, (int64_t)frames * (4 * d->N + d->cfg.K / 8));
         if (e == hipSuccess) e = ldpc::fused_run(&d->fused, run, s, &d->last_iterations);
         if (e == hipSuccess) e = span_end(d, s);
@@ -973,13 +979,29 @@ int ldpc_decoder_dump(ldpc_decoder *d, int32_t which, float *host_out, int64_t c
     const int64_t frames = d->last_frames;
     const int V = d->V, F = d->F;
     const int tiles = (int)((frames + F - 1) / F);
+    if (d->use_fused && d->cfg.algo == LDPC_ALGO_SP) {
+        if (!d->fused.dump_p) return fail(LDPC_ERR_STATE, "fused dump needs set_tap() before the decode");
+        const int64_t per = (which == 0 || which == 1) ? d->E : d->N;
+        if (which < 0 || which > 3 || count != frames * per) return fail(LDPC_ERR_ARG, "bad `which`/count");
+        if (which == 3) {
+            std::vector<uint8_t> b((size_t)count);
+            HIP_TRY(hipMemcpy(b.data(), d->fused.dump_b, (size_t)count, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < count; ++i) host_out[i] = (float)b[i];
+            return LDPC_OK;
+        }
+        const float *src = which == 0 ? d->fused.dump_r : (which == 1 ? d->fused.dump_q : d->fused.dump_p);
+        HIP_TRY(hipMemcpy(host_out, src, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+        return LDPC_OK;
+    }
     if (d->use_fused) {
         const float *src = which == 0 ? d->fused.dump_r : (which == 2 ? d->fused.dump_p : nullptr);
         const int64_t per = which == 0 ? d->E : d->N;
         if (which == 3) {           /* hard bits = P < 0 */
             if (!d->fused.dump_p || count != frames * d->N) return fail(LDPC_ERR_ARG, "fused dump needs set_tap() and count = frames*N");
             HIP_TRY(hipMemcpy(host_out, d->fused.dump_p, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
-            for (int64_t i = 0; i < count; ++i) host_out[i] = host_out[i] < 0.0f ? 1.0f : 0.0f;
+            const bool notpos = d->cfg.algo == LDPC_ALGO_MS;      /* MS chain: bit = !(p > 0) */
+            for (int64_t i = 0; i < count; ++i)
+                host_out[i] = (notpos ? !(host_out[i] > 0.0f) : (host_out[i] < 0.0f)) ? 1.0f : 0.0f;
             return LDPC_OK;
         }
         if (!src || count != frames * per) return fail(LDPC_ERR_ARG, "fused dump: set_tap() first; which in {0,2,3}");

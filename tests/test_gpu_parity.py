@@ -167,6 +167,31 @@ def test_min_sum_fused_and_streaming_paths_agree(built, monkeypatch):
             dec.close()
 
 
+def test_sum_product_fused_and_streaming_paths_agree(built, monkeypatch):
+    """DecodeSP on short QC codes: the probability-domain sum-product in one LDS-resident launch
+    (fused_sp_kernel) against the streaming kernels and the oracle, messages included."""
+    for rate, N, sigma, B in ((4, 576, 0.5, 70), (0, 648, 0.75, 9), (0, 1152, 0.85, 9), (5, 960, 0.42, 40), (1, 672, 0.6, 12)):
+        g, og, K, M, z = _graph(rate, N)
+        y = channel.awgn_frames(N, 0, B, sigma, seed=16)
+        want = oracle.decode(og, y, "sp", tap_iter=2)
+        for fused in ("1", "0"):
+            monkeypatch.setenv("LDPC_TUNE_FUSED", fused)
+            dec = L.Decoder(g, K, max_batch=B, algo="sp", layer_rows=z)
+            out, iters = dec.decode(y)
+            assert np.array_equal(out, want["out"]) and np.array_equal(iters, want["iters"]), (rate, N, fused)
+            assert np.array_equal(dec.decode(y[:1])[0], oracle.decode(og, y[:1], "sp")["out"])
+            dec.set_tap(2)
+            dec.decode(y)
+            run_r = np.nonzero(want["iters"] >= 2)[0]
+            run_q = np.nonzero(want["iters"] > 2)[0]
+            R, Q = dec.dump(0, B), dec.dump(1, B)
+            assert np.array_equal(((f32(1) + R) * f32(0.5))[run_r], want["taps"]["r0"][run_r], equal_nan=True), fused
+            assert np.array_equal(((f32(1) - R) * f32(0.5))[run_r], want["taps"]["r1"][run_r], equal_nan=True), fused
+            dq = want["taps"]["q0"] - want["taps"]["q1"]
+            assert np.array_equal(Q[run_q], dq[run_q], equal_nan=True), fused
+            dec.close()
+
+
 @pytest.mark.parametrize("algo", ["ms", "sp", "layered"])
 def test_ragged_batches_and_chunking(built, algo):
     """frames not a multiple of the tile, more frames than max_batch (Coder::decode's
@@ -222,7 +247,7 @@ def test_degenerate_channel_values(built, algo, monkeypatch):
     y[9, :] = -1.0
     y[10, rng.choice(N, 300, replace=False)] *= 400.0             # magnitudes beyond the 1000 clip
     y[11, ::2] = 0.0
-    for fused in (("1", "0") if algo == "layered" else ("1",)):
+    for fused in (("1",) if algo == "ms_fused" else ("1", "0")):
         monkeypatch.setenv("LDPC_TUNE_FUSED", fused)
         dec = L.Decoder(g, K, max_batch=24, algo=algo, max_iter=15, layer_rows=z)
         out, iters = dec.decode(y)
