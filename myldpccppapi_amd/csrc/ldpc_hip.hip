@@ -486,6 +486,45 @@ int build_classes(ldpc_decoder *d, const ldpc_graph *g)
     return LDPC_OK;
 }
 
+/* HBM message arrays, per-degree work lists and kernel tables of a streaming flooding decoder. */
+int setup_flooding(ldpc_decoder *d, const ldpc_graph *g, size_t TF)
+{
+    const ldpc_decoder_config *cfg = &d->cfg;
+    d->msg_size = cfg->msg_dtype == LDPC_MSG_F16 ? 2 : 4;
+    HIP_TRY(d->chan.alloc(TF * d->N * d->msg_size));
+    HIP_TRY(d->Q.alloc(TF * (size_t)d->E * d->msg_size));
+    HIP_TRY(d->R.alloc(TF * (size_t)d->E * d->msg_size));
+    int rc = build_classes(d, g);
+    if (rc) return rc;
+    constexpr int DM = ldpc::kMaxUnrolledDegree;
+    constexpr int DH = ldpc::kMaxUnrolledCheckDegreeMS;
+    using ldpc::hf;
+    using ldpc::kAlgoMS;
+    using ldpc::kAlgoSP;
+#define LDPC_FILL(ALGO, TYPE, VV)                                                      \
+    do {                                                                               \
+        FloodTable<ALGO, VV, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn); \
+        LinkTable<ALGO, VV, TYPE, DM>::fill(d->link_fn);                               \
+        d->init_fn = pick_init<ALGO, TYPE>(VV);                                        \
+        if (ALGO == kAlgoMS) {   /* min-sum rows of degree 17..32: narrow unrolled kernels */ \
+            CheckTableMS<VV, TYPE, DH>::fill(d->check_fn, d->check_fn_wide);           \
+            d->max_check_unrolled = DH;                                                \
+        }                                                                              \
+    } while (0)
+#define LDPC_FILL_V(ALGO, TYPE)                 \
+    do {                                        \
+        if (d->V == 1) LDPC_FILL(ALGO, TYPE, 1); \
+        else if (d->V == 2) LDPC_FILL(ALGO, TYPE, 2); \
+        else LDPC_FILL(ALGO, TYPE, 4);          \
+    } while (0)
+    if (cfg->algo == LDPC_ALGO_SP) LDPC_FILL_V(kAlgoSP, float);
+    else if (cfg->msg_dtype == LDPC_MSG_F16) LDPC_FILL_V(kAlgoMS, hf);
+    else LDPC_FILL_V(kAlgoMS, float);
+#undef LDPC_FILL_V
+#undef LDPC_FILL
+    return LDPC_OK;
+}
+
 }  // namespace
 
 /* ================================================================== C ABI */
@@ -690,40 +729,9 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
             }
         }
         if (!d->use_fused) {
-        d->msg_size = cfg->msg_dtype == LDPC_MSG_F16 ? 2 : 4;
-            HIP_TRY(d->chan.alloc(TF * d->N * d->msg_size));
-            HIP_TRY(d->Q.alloc(TF * (size_t)d->E * d->msg_size));
-            HIP_TRY(d->R.alloc(TF * (size_t)d->E * d->msg_size));
-            int rc = build_classes(d, g);
+            int rc = setup_flooding(d, g, TF);
             if (rc) return rc;
-            constexpr int DM = ldpc::kMaxUnrolledDegree;
-            using ldpc::kAlgoMS;
-            using ldpc::kAlgoSP;
-            using ldpc::hf;
-    #define LDPC_FILL(ALGO, TYPE)                                                                          \
-        do {                                                                                               \
-            if (d->V == 1) FloodTable<ALGO, 1, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);  \
-            else if (d->V == 2) FloodTable<ALGO, 2, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn); \
-            else FloodTable<ALGO, 4, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn);            \
-            d->init_fn = pick_init<ALGO, TYPE>(d->V);                                                      \
-            if (d->V == 1) LinkTable<ALGO, 1, TYPE, DM>::fill(d->link_fn);                                 \
-            else if (d->V == 2) LinkTable<ALGO, 2, TYPE, DM>::fill(d->link_fn);                            \
-            else LinkTable<ALGO, 4, TYPE, DM>::fill(d->link_fn);                                           \
-        } while (0)
-    #define LDPC_FILL_MS_HIGH(TYPE)                                                                         \
-        do {                                                                                               \
-            constexpr int DH = ldpc::kMaxUnrolledCheckDegreeMS;                                            \
-            if (d->V == 1) CheckTableMS<1, TYPE, DH>::fill(d->check_fn, d->check_fn_wide);                 \
-            else if (d->V == 2) CheckTableMS<2, TYPE, DH>::fill(d->check_fn, d->check_fn_wide);            \
-            else CheckTableMS<4, TYPE, DH>::fill(d->check_fn, d->check_fn_wide);                           \
-            d->max_check_unrolled = DH;                                                                    \
-        } while (0)
-            if (cfg->algo == LDPC_ALGO_SP) LDPC_FILL(kAlgoSP, float);
-            else if (cfg->msg_dtype == LDPC_MSG_F16) { LDPC_FILL(kAlgoMS, hf); LDPC_FILL_MS_HIGH(hf); }
-            else { LDPC_FILL(kAlgoMS, float); LDPC_FILL_MS_HIGH(float); }
-    #undef LDPC_FILL
-    #undef LDPC_FILL_MS_HIGH
-    }
+        }
     }
     *out = guard.release();
     return LDPC_OK;
