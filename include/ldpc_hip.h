@@ -158,7 +158,9 @@ typedef struct ldpc_kernel_time {
     float ms_total;        /* sum of HIP-event durations of those launches             */
     int64_t bytes_total;   /* ALGORITHMIC bytes of those launches: 4 B per message read
                               or written + 4 B per channel value read, per frame        */
-    char name[64];         /* e.g. "check_kernel<sp,7,4>" (algo, degree, frames/lane)  */
+    char name[64];         /* e.g. "check_link_kernel<sp,7,4>" (algo, degree, frames/lane), the
+                              kernel's name in a rocprofv3 trace up to the spelling of the
+                              template arguments                                        */
 } ldpc_kernel_time;
 int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t capacity,
                               int32_t *count);

@@ -905,7 +905,8 @@ inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int
     } else if (r.flooding) {
         LDPC_FUSED_BY_MW(fused_flood_kernel, LDPC_COMMA false)
     } else if (pl->z <= 32 && !getenv("LDPC_TUNE_NO_PACK")) {
-        const int G = 64 / pl->z;
+        int G = 64 / pl->z;
+        while (G > 1 && (size_t)G * pl->lds_per_frame > 60 * 1024) --G;   /* default dynamic-LDS limit */
         const unsigned pgrid = (unsigned)((r.frames + G - 1) / G);
         const size_t plds = G * pl->lds_per_frame;
         if (dm == 8) fused_layered_packed_kernel<8><<<pgrid, 64, plds, s>>>(a, G);

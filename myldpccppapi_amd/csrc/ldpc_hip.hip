@@ -134,10 +134,15 @@ template <int V, typename T> struct CheckTableMS<V, T, ldpc::kMaxUnrolledDegree>
 
 using LinkFn = void (*)(const ldpc::CheckArgs, const ldpc::LinkArgs);
 template <int ALGO, int V, typename T, int D> struct LinkTable {
-    static void fill(LinkFn *t) { t[D] = ldpc::check_link_kernel<ALGO, D, V, T>; LinkTable<ALGO, V, T, D - 1>::fill(t); }
+    static void fill(LinkFn *t, LinkFn *tn)
+    {
+        t[D] = ldpc::check_link_kernel<ALGO, D, V, T>;
+        tn[D] = ldpc::check_link_narrow_kernel<ALGO, D, V, T>;
+        LinkTable<ALGO, V, T, D - 1>::fill(t, tn);
+    }
 };
 template <int ALGO, int V, typename T> struct LinkTable<ALGO, V, T, 1> {
-    static void fill(LinkFn *) {}
+    static void fill(LinkFn *, LinkFn *) {}
 };
 
 using InitFn = void (*)(const ldpc::InitArgs);
@@ -164,7 +169,7 @@ struct ColClass {
 
 struct TimedSpan {
     hipEvent_t a, b;
-    int kind;       /* 0 check, 1 var, 2 layer, 3 other */
+    int kind;       /* 0 check, 1 var, 2 layer, 3 other, 4 check with column-local fusion */
     int degree;
     int64_t bytes;  /* algorithmic bytes of the launch */
 };
@@ -189,7 +194,9 @@ struct ldpc_decoder {
     CheckFn check_fn[ldpc::kMaxUnrolledCheckDegreeMS + 1] = {};      /* narrow waves (1 value per lane) */
     CheckFn check_fn_wide[ldpc::kMaxUnrolledCheckDegreeMS + 1] = {}; /* V values per lane */
     int max_check_unrolled = ldpc::kMaxUnrolledDegree;
-    LinkFn link_fn[ldpc::kMaxUnrolledDegree + 1] = {};
+    LinkFn link_fn[ldpc::kMaxUnrolledDegree + 1] = {};        /* wide waves */
+    LinkFn link_narrow_fn[ldpc::kMaxUnrolledDegree + 1] = {}; /* narrow waves */
+    int tune_link_narrow = 1;           /* LDPC_TUNE_LINK_NARROW=0: wide linked check kernel */
     int link_rpw = 16;                  /* rows per wave of the fused check kernel; 0 = fusion off */
     VarFn var_fn[ldpc::kMaxUnrolledDegree + 1] = {};
 
@@ -333,16 +340,17 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
         for (auto &rc : d->row_classes) {
             /* algorithmic bytes: the fused columns' messages and channel values count as in the
              * two-kernel formulation (16 E + 4 N per frame-iteration in total) */
-            HIP_TRY(span_begin(d, s, 0, rc.degree,
+            HIP_TRY(span_begin(d, s, rc.linked ? 4 : 0, rc.degree,
                                (2 * msz * rc.degree * rc.count + msz * 5 * rc.linked) * frames));
             CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree};
             if (rc.linked) {
                 LinkArgs lk{rc.link_col.p, rc.link_pos.p, d->chan.p, d->Q.p, d->hard.p, d->N,
                             (it < max_iter) ? 1 : 0, d->tap_iter ? 1 : 0};
                 a.rows_per_wave = d->link_rpw;
-                const int waves = (rc.count + d->link_rpw - 1) / d->link_rpw;
+                const bool nar = d->tune_link_narrow != 0;
+                const int waves = ((rc.count + d->link_rpw - 1) / d->link_rpw) * (nar ? V : 1);
                 dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
-                d->link_fn[rc.degree]<<<grid, kBlock, 0, s>>>(a, lk);
+                (nar ? d->link_narrow_fn : d->link_fn)[rc.degree]<<<grid, kBlock, 0, s>>>(a, lk);
                 HIP_TRY(span_end(d, s));
                 continue;
             }
@@ -504,7 +512,7 @@ int setup_flooding(ldpc_decoder *d, const ldpc_graph *g, size_t TF)
 #define LDPC_FILL(ALGO, TYPE, VV)                                                      \
     do {                                                                               \
         FloodTable<ALGO, VV, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn); \
-        LinkTable<ALGO, VV, TYPE, DM>::fill(d->link_fn);                               \
+        LinkTable<ALGO, VV, TYPE, DM>::fill(d->link_fn, d->link_narrow_fn);            \
         d->init_fn = pick_init<ALGO, TYPE>(VV);                                        \
         if (ALGO == kAlgoMS) {   /* min-sum rows of degree 17..32: narrow unrolled kernels */ \
             CheckTableMS<VV, TYPE, DH>::fill(d->check_fn, d->check_fn_wide);           \
@@ -670,6 +678,7 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     if (const char *e = getenv("LDPC_TUNE_SYN_XCD")) d->tune_syn_xcd = atoi(e);
     if (const char *e = getenv("LDPC_TUNE_CHECK_WIDE")) d->tune_check_wide = atoi(e);
     if (const char *e = getenv("LDPC_TUNE_LINK_RPW")) d->link_rpw = atoi(e);
+    if (const char *e = getenv("LDPC_TUNE_LINK_NARROW")) d->tune_link_narrow = atoi(e);
     d->V = pick_frames_per_lane(*cfg, g->max_row_deg, g->max_col_deg);
     d->F = 64 * d->V;
     d->T = (cfg->max_batch + d->F - 1) / d->F;
@@ -928,7 +937,7 @@ int ldpc_decoder_stats(ldpc_decoder *d, ldpc_decode_stats *st)
     for (size_t i = 0; i < d->spans_used; ++i) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, d->spans[i].a, d->spans[i].b));
-        if (d->spans[i].kind == 0) { st->ms_check += ms; ++st->launches_check; }
+        if (d->spans[i].kind == 0 || d->spans[i].kind == 4) { st->ms_check += ms; ++st->launches_check; }
         else if (d->spans[i].kind == 1 || d->spans[i].kind == 2) { st->ms_var += ms; ++st->launches_var; }
         else st->ms_other += ms;
     }
@@ -942,7 +951,8 @@ int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t ca
     if (!d->have_last) return fail(LDPC_ERR_STATE, "no decode call to report on");
     HIP_TRY(hipSetDevice(d->cfg.device));
     HIP_TRY(hipEventSynchronize(d->ev_end));
-    static const char *phase_name[] = {"check_kernel", "var_kernel", "layer_kernel", "other"};
+    const char *phase_name[] = {"check_kernel", "var_kernel", "layer_kernel", "other",
+                                d->tune_link_narrow ? "check_link_narrow_kernel" : "check_link_kernel"};
     static const char *algo_name_f32[] = {"sp", "ms", "layered", "ms_fused"};
     static const char *algo_name_f16[] = {"sp16", "ms16", "layered16", "ms_fused16"};
     const char **algo_name = d->msg_size == 2 ? algo_name_f16 : algo_name_f32;
@@ -952,12 +962,12 @@ int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t ca
         HIP_TRY(hipEventElapsedTime(&ms, sp.a, sp.b));
         int k = 0;
         for (; k < *count; ++k)
-            if (out[k].phase == sp.kind && out[k].degree == sp.degree) break;
+            if (out[k].phase == (sp.kind == 4 ? 0 : sp.kind) && out[k].degree == sp.degree) break;
         if (k == *count) {
             if (*count == capacity) continue;
             ++*count;
             memset(&out[k], 0, sizeof out[k]);
-            out[k].phase = sp.kind;
+            out[k].phase = sp.kind == 4 ? 0 : sp.kind;      /* both are the check phase */
             out[k].degree = sp.degree;
             if (sp.kind == 3) snprintf(out[k].name, sizeof out[k].name, "other");
             else snprintf(out[k].name, sizeof out[k].name, "%s<%s,%d,%d>", phase_name[sp.kind],

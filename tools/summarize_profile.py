@@ -30,11 +30,10 @@ def short(name):
 
 def display(name):
     """check_kernel<0, 7, 4> -> check_kernel<sp,7,4> (the names bench.py prints)"""
-    m = re.match(r"(check_kernel|check_link_kernel|var_kernel)<(\d), (\d+), (\d)(?:, \d)?, (float|_Float16)>", name)
+    m = re.match(r"(check_kernel|check_link_kernel|check_link_narrow_kernel|var_kernel)<(\d), (\d+), (\d)(?:, \d)?, (float|_Float16)>", name)
     if m:
         algo = ("sp", "ms")[int(m.group(2))] + ("16" if m.group(5) != "float" else "")
-        # bench.py names kernels by phase: the linked check kernel is the check phase of its degree
-        return "%s<%s,%s,%s>" % ("check_kernel" if m.group(1) != "var_kernel" else "var_kernel", algo, m.group(3), m.group(4))
+        return "%s<%s,%s,%s>" % (m.group(1), algo, m.group(3), m.group(4))
     m = re.match(r"layer_kernel<(\d+), (\d)>", name)
     if m:
         return "layer_kernel<layered,%s,%s>" % (m.group(1), m.group(2))
@@ -82,7 +81,7 @@ for k, v in pmc.items():
         # wave-instruction): every Q byte is read exactly once (no reuse is possible), the
         # algorithmic read volume is 3.716 GB per launch and the raw counter shows 1.859 GB,
         # i.e. exactly 1/2 as well.
-        wide = bool(re.search(r"^(var_kernel|layer_kernel|check_kernel|check_link_kernel)<", k))
+        wide = bool(re.search(r"^(var_kernel|layer_kernel|check_kernel|check_link_kernel|check_link_narrow_kernel)<", k))
         fetch = v["FETCH_SIZE_KiB_per_launch"] * 1024 * (2 if wide else 1)
         write = v["WRITE_SIZE_KiB_per_launch"] * 1024
         v["fetch_correction"] = 2 if wide else 1
