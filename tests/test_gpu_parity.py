@@ -392,6 +392,36 @@ def test_device_buffers_and_misuse(built):
         L.Decoder(g, K, 8, algo="ms", device=99)
 
 
+def test_two_decoders_on_two_host_threads(built):
+    """A handle is not re-entrant, but different handles may run concurrently from different host
+    threads (thread-local error state, no shared mutable statics): each thread's results must be
+    those of a serial run."""
+    import threading
+    g1, og1, K1, M1, z1 = _graph(codes.RATE_1_2, 1152)
+    g2, og2, K2, M2, z2 = _graph(codes.RATE_3_4_A, 960)
+    y1 = channel.awgn_frames(1152, 0, 300, 0.85, seed=17)
+    y2 = channel.awgn_frames(960, 0, 300, 0.6, seed=18)
+    w1 = oracle.decode(og1, y1, "sp")
+    w2 = oracle.decode(og2, y2, "layered", layer_rows=z2)
+    d1 = L.Decoder(g1, K1, max_batch=128, algo="sp", frames_per_lane=2)          # streaming, 3 groups
+    d2 = L.Decoder(g2, K2, max_batch=300, algo="layered", layer_rows=z2)         # fused
+    res = {}
+
+    def work(name, dec, y):
+        for _ in range(4):
+            res[name] = dec.decode(y)
+
+    ts = [threading.Thread(target=work, args=("a", d1, y1)), threading.Thread(target=work, args=("b", d2, y2))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert np.array_equal(res["a"][0], w1["out"]) and np.array_equal(res["a"][1], w1["iters"])
+    assert np.array_equal(res["b"][0], w2["out"]) and np.array_equal(res["b"][1], w2["iters"])
+    d1.close()
+    d2.close()
+
+
 def test_cpp_coder_round_trip_like_test_cpp(built, tmp_path):
     """The reference's own pass signal (Test.cpp:105-110): ErrNum=0 after encode -> AWGN ->
     decode, for every decode mode of the C++ Coder class."""
