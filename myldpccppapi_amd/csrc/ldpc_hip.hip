@@ -203,6 +203,7 @@ struct ldpc_decoder {
     ldpc::LayeredPlan layered;          /* LDPC_ALGO_LAYERED, streaming (one launch per layer) */
     ldpc::FusedPlan fused;              /* LDPC_ALGO_LAYERED, short QC codes: whole decode in LDS */
     bool use_fused = false;
+    bool use_ldsp = false;              /* layered: posterior in LDS, check records in cache */
 
     /* staging for the host-buffer entry point: two slots, so the H2D copy of group k+1
      * (copy_stream) overlaps the decode of group k (stream) */
@@ -714,9 +715,20 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
         if (!(fe && atoi(fe) == 0) && (cfg->pack_mode == LDPC_PACK_BYTES || cfg->K % 8 == 0)) {
             HIP_TRY(ldpc::fused_plan_create(&d->fused, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows));
             d->use_fused = d->fused.eligible;
+            /* larger QC codes whose posteriors still fit in LDS: layered_ldsp_kernel
+             * (LDPC_TUNE_LDSP=0 keeps the streaming kernels, =1 prefers it over the fully fused one) */
+            const char *le = getenv("LDPC_TUNE_LDSP");
+            if (d->fused.eligible_ldsp && cfg->msg_dtype == LDPC_MSG_F32 &&
+                (le ? atoi(le) != 0 : !d->use_fused)) {
+                HIP_TRY(ldpc::ldsp_prepare(&d->fused, cfg->max_batch, cfg->device));
+                d->use_fused = true;
+                d->use_ldsp = true;
+            }
         }
-        int rc = ldpc::layered_plan_create(&d->layered, g->M, g->N, g->E, g->row_ptr, g->cols,
-                                           cfg->layer_rows, d->T, d->V);
+        /* the streaming plan (and its P / R arrays in HBM) only when no LDS-resident kernel applies;
+         * a detected QC structure already implies that rows of a layer share no column */
+        int rc = d->use_fused ? 0 : ldpc::layered_plan_create(&d->layered, g->M, g->N, g->E, g->row_ptr, g->cols,
+                                                              cfg->layer_rows, d->T, d->V);
         if (rc == -1) return fail(LDPC_ERR_ARG, "layer_rows=%d must divide M=%d and rows of a layer "
                                   "must not share a column", cfg->layer_rows, g->M);
         if (rc) return fail(LDPC_ERR_HIP, "layered plan allocation failed: %s",
@@ -783,7 +795,9 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
                            d->cfg.algo == LDPC_ALGO_MS_FUSED ? 1 : (d->cfg.algo == LDPC_ALGO_MS ? 2 : (d->cfg.algo == LDPC_ALGO_SP ? 3 : 0)),
                            d->cfg.llr_scale};
         hipError_t e = span_begin(d, s, 2, 0, (int64_t)frames * (4 * d->N + d->cfg.K / 8));
-        if (e == hipSuccess) e = ldpc::fused_run(&d->fused, run, s, &d->last_iterations);
+        if (e == hipSuccess)
+            e = d->use_ldsp ? ldpc::ldsp_run(&d->fused, run, s, &d->last_iterations)
+                            : ldpc::fused_run(&d->fused, run, s, &d->last_iterations);
         if (e == hipSuccess) e = span_end(d, s);
         rc = (e == hipSuccess) ? LDPC_OK : fail(LDPC_ERR_HIP, "fused decode: %s", hipGetErrorString(e));
     } else if (d->cfg.algo == LDPC_ALGO_LAYERED) {

@@ -110,7 +110,7 @@ def test_high_rate_check_degree_30(built):
         dec.close()
 
 
-def test_layered_bg1_profile_z384(built):
+def test_layered_bg1_profile_z384(built, monkeypatch):
     """configs[3] shape: BG1-profile QC code, Z = 384 (N = 26112, E = 121344), layered
     min-sum with 384-row layers.  Two frames against the oracle bit for bit, and the
     codeword symmetry over the whole batch."""
@@ -138,6 +138,27 @@ def test_layered_bg1_profile_z384(built):
     kb = Kb // 8
     assert np.array_equal(out0[:kb], o["out"][:kb]) and np.array_equal(out0[69 * kb:], o["out"][kb:])
     assert it0[0] == o["iters"][0] and it0[69] == o["iters"][1]
+    dec.set_tap(2)
+    dec.decode(y0)
+    r_ldsp, p_ldsp = dec.dump(0, B), dec.dump(2, B)
+    dec.close()
+    # the default above is layered_ldsp_kernel (posterior in LDS); the one-launch-per-layer
+    # streaming kernels must give the same bits, iteration counts and messages for all 70 frames
+    monkeypatch.setenv("LDPC_TUNE_LDSP", "0")
+    dec = L.Decoder(g, Kb, max_batch=B, algo="layered", max_iter=20, layer_rows=Z)
+    out1, it1 = dec.decode(y0)
+    assert np.array_equal(out1, out0) and np.array_equal(it1, it0)
+    dec.set_tap(2)
+    dec.decode(y0)
+    run = np.nonzero(it0 >= 2)[0]
+    assert np.array_equal(dec.dump(0, B)[run], r_ldsp[run]) and np.array_equal(dec.dump(2, B)[run], p_ldsp[run])
+    dec.close()
+    # fewer persistent workgroups than frames
+    monkeypatch.setenv("LDPC_TUNE_LDSP", "1")
+    monkeypatch.setenv("LDPC_TUNE_LDSP_GRID", "16")
+    dec = L.Decoder(g, Kb, max_batch=B, algo="layered", max_iter=20, layer_rows=Z)
+    out2, it2 = dec.decode(y0)
+    assert np.array_equal(out2, out0) and np.array_equal(it2, it0)
     dec.close()
 
 

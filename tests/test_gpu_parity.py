@@ -127,8 +127,12 @@ def test_layered_streaming_and_fused_paths_agree(built, monkeypatch):
         g, og, K, M, z = _graph(rate, N)
         y = channel.awgn_frames(N, 0, B, sigma, seed=13)
         want = oracle.decode(og, y, "layered", layer_rows=z, tap_iter=3)
-        for fused in ("1", "0"):
-            monkeypatch.setenv("LDPC_TUNE_FUSED", fused)
+        # "ldsp": posterior in LDS, 16-byte check records in cache (layered_ldsp_kernel), here with a
+        # grid of 4 persistent workgroups so that each one walks over several frames
+        for fused in ("1", "ldsp", "0"):
+            monkeypatch.setenv("LDPC_TUNE_FUSED", "1" if fused == "ldsp" else fused)
+            monkeypatch.setenv("LDPC_TUNE_LDSP", "1" if fused == "ldsp" else "0")
+            monkeypatch.setenv("LDPC_TUNE_LDSP_GRID", "4")
             dec = L.Decoder(g, K, max_batch=B, algo="layered", layer_rows=z)
             out, iters = dec.decode(y)
             assert np.array_equal(out, want["out"]) and np.array_equal(iters, want["iters"]), (rate, N, fused)
@@ -247,8 +251,9 @@ def test_degenerate_channel_values(built, algo, monkeypatch):
     y[9, :] = -1.0
     y[10, rng.choice(N, 300, replace=False)] *= 400.0             # magnitudes beyond the 1000 clip
     y[11, ::2] = 0.0
-    for fused in (("1",) if algo == "ms_fused" else ("1", "0")):
-        monkeypatch.setenv("LDPC_TUNE_FUSED", fused)
+    for fused in (("1",) if algo == "ms_fused" else (("1", "ldsp", "0") if algo == "layered" else ("1", "0"))):
+        monkeypatch.setenv("LDPC_TUNE_FUSED", "1" if fused == "ldsp" else fused)
+        monkeypatch.setenv("LDPC_TUNE_LDSP", "1" if fused == "ldsp" else "0")
         dec = L.Decoder(g, K, max_batch=24, algo=algo, max_iter=15, layer_rows=z)
         out, iters = dec.decode(y)
         want = oracle.decode(og, y, algo, max_iter=15, layer_rows=z)
