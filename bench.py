@@ -93,6 +93,13 @@ def run_extra(name, args):
     frame_iters = float(iters.sum())
     kb = sum(k["bytes_total"] for k in kt)
     kms = sum(k["ms_total"] for k in kt)
+    one_launch = len(kt) == 1 and ("ldsp" in kt[0]["name"] or "fused" in kt[0]["name"])
+    hbm_moved = kb
+    if one_launch:
+        # LDS / cache resident decode: the kernel's HBM traffic is the channel values and the packed
+        # bits only; `achieved` stays SURVEY section 8(d)'s algorithmic figure of the schedule
+        # (16 E bytes per frame-iteration) over the kernel's time, so it can exceed the HBM peak
+        kb = bytes_fi * frame_iters * args.steps
     res = {"metric": "decoded Mbit/s (info bits)", "value": round(B * K / dt / 1e6, 2), "unit": "Mbit/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),
            "higher_is_better": True, "dtype": "f16" if c["msg"] == "f16" else "f32", "data": "synthetic",
@@ -108,6 +115,10 @@ def run_extra(name, args):
                         "per_kernel": {k["name"]: {"avg_ms": round(k["ms_total"] / k["launches"], 4),
                                                    "GB/s": round(k["bytes_total"] / (k["ms_total"] * 1e-3) / 1e9, 1)}
                                        for k in sorted(kt, key=lambda k: -k["ms_total"])[:6]}}}
+    if one_launch:
+        res["roofline"]["note"] = ("one launch, frame state in LDS and check records in L2/Infinity Cache: "
+                                   "achieved = algorithmic bytes of the layered schedule / kernel time, not HBM traffic")
+        res["roofline"]["hbm_bytes_per_launch"] = int(hbm_moved / max(1, kt[0]["launches"]))
     print(json.dumps(res), flush=True)
     dec.close()
 

@@ -716,283 +716,6 @@ __global__ __launch_bounds__(64 * MW) void fused_sp_kernel(const FusedArgs a)
     }
 }
 
-
-/* ------------------------------------------------------------------------------------------
- * Layered min-sum for quasi-cyclic codes too large for the kernels above (5G-NR BG1 at Z = 384:
- * N = 26112, E = 121344): the posteriors P[N] of ONE frame live in LDS (104 KB of the CU's
- * 160 KB), and the check-to-variable messages are not kept as E floats at all.  A min-sum row
- * sends only two magnitudes: R_k = s_k * (k == argmin ? ac : ab) with s_k = sign(q_k) in
- * {+1, -1, +0, -0}, so a row's whole message set is the 16-byte record
- *     { ab, ac, 2-bit codes of s_0..s_15, codes of s_16..s_23 | argmin << 16 }
- * from which the next iteration recomputes every R_k with the SAME multiplication the streaming
- * kernel performed before storing it: results are bit-identical (layer_kernel / oracle).
- * Row r of every layer is always handled by lane r of the same workgroup, so a record is read
- * and written by one thread only (no fences), as ONE 16-byte load and store per row and
- * iteration, the next layer's record requested before the current layer is worked on.
- * Workgroups are persistent (grid = what fits on the chip at once) and walk over the frames, so
- * the records of all resident workgroups (M * 16 B each, 72 MB chip-wide at BG1 Z = 384) stay
- * in L2 / Infinity Cache: HBM sees the channel values once and the packed bits once.
- * Algorithmic traffic of the streaming formulation (16 E B per frame-iteration) vs here:
- * 32 M B through the cache hierarchy, nothing through HBM.  Early termination is per frame. */
-/* The kernel below stores to global memory inside its layer loop, so the compiler may no longer
- * assume that the code tables are unchanged and would fetch them with per-lane vector loads and a
- * full memory round trip per layer; read through the constant address space they stay scalar
- * loads (the tables are written once, by the host, before any launch). */
-typedef const int32_t __attribute__((address_space(4))) *ldpc_const_i32;
-__device__ __forceinline__ ldpc_const_i32 as_constant(const int32_t *p) { return (ldpc_const_i32)(uintptr_t)p; }
-
-/* Workgroup barrier that orders LDS traffic only: the global loads / stores of this kernel are
- * private to their thread, and waiting for them (what __syncthreads() does) would put a memory
- * round trip into every layer step. */
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-/* Check record (16 B per row and iteration):
- *   x = bits of ab = sign(prod) * min1      y = bits of ac = sign(prod) * min2
- *   z = 2-bit codes of entries 0..15        w = codes of entries 16..23 | argmin << 16 | irregular << 21
- * code of entry k: bit 0 = sign bit of q_k (0 for NaN), bit 1 = "q_k is zero or NaN".  The message
- * the streaming kernel stores, R_k = cl_sign(q_k) * (k == argmin ? ac : ab), is then
- *   bits(R_k) = (bits(sel) ^ (code & 1) << 31) & (code & 2 ? 0x80000000 : 0xffffffff)
- * exactly: cl_sign(q) is +-1 for a regular q (the product only flips the sign, also of a zero sel),
- * +-0 for q = +-0 (a zero with the xor of the signs) and +0 for NaN (a zero with sel's sign); sel is
- * always finite (min1, min2 <= 1001).  `irregular` = some code has bit 1 set. */
-constexpr uint32_t kLdspIrregular = 1u << 21;
-
-__device__ __forceinline__ bool ldsp_regular(uint32_t bits)      /* finite non-zero or infinite */
-{
-    return ((bits & 0x7fffffffu) - 1u) < 0x7f800000u;
-}
-
-__device__ __forceinline__ uint32_t ldsp_old_message(const uint4 old, int k)
-{
-    const uint32_t c2 = ((k < 16 ? old.z : old.w) >> ((k & 15) * 2)) & 3u;
-    const uint32_t sel = (k == ((int)(old.w >> 16) & 31)) ? old.y : old.x;
-    return (sel ^ ((c2 & 1u) << 31)) & ((c2 & 2u) ? 0x80000000u : 0xffffffffu);
-}
-
-/* Any input: the reference's operations one by one (decodeCL.c:345-383), run-time loops, q parked
- * in P between the two passes as the reference does.  Taken by a wave only when one of its rows
- * meets a zero, a NaN or an underflowed product. */
-__device__ __forceinline__ uint4 ldsp_layer_row_any(float *P, ldpc_const_i32 pk, int d, int z, int r, const uint4 old)
-{
-    float prod = 1.0f, b = 1000.0f, c = 1001.0f;
-    int bind = 31;
-    for (int k = 0; k < d; ++k) {
-        const int ent = pk[k];
-        int t = r + (ent & 0xffff);
-        t = t >= z ? t - z : t;
-        const int col = (ent >> 16) * z + t;
-        const float q = P[col] - __uint_as_float(ldsp_old_message(old, k));
-        P[col] = q;
-        prod *= q;
-        const float mag = __builtin_fabsf(q);
-        if (mag <= b) { c = b; b = mag; bind = k; }
-        else if (mag > b && mag <= c) { c = mag; }
-    }
-    const float sa = cl_sign(prod);
-    const float ab = sa * b, ac = sa * c;
-    uint32_t lo = 0, hi = 0;
-    for (int k = 0; k < d; ++k) {
-        const int ent = pk[k];
-        int t = r + (ent & 0xffff);
-        t = t >= z ? t - z : t;
-        const int col = (ent >> 16) * z + t;
-        const float q = P[col];
-        const float rn = cl_sign(q) * ((k == bind) ? ac : ab);
-        P[col] = q + rn;
-        const uint32_t qb = __float_as_uint(q);
-        const bool nan = (qb & 0x7fffffffu) > 0x7f800000u;
-        const uint32_t code = (nan ? 0u : qb >> 31) | (ldsp_regular(qb) ? 0u : 2u);
-        if (k < 16) lo |= code << (k * 2);
-        else hi |= code << ((k - 16) * 2);
-    }
-    if ((lo & 0xaaaaaaaau) | (hi & 0xaaaau)) hi |= kLdspIrregular;
-    hi |= (uint32_t)bind << 16;
-    return uint4{__float_as_uint(ab), __float_as_uint(ac), lo, hi};
-}
-
-/* Exact row width D, straight-line code.  Fast path: every q of every row of the wave regular
- * (checked through the old records' flag and through the products: a zero or NaN q makes the
- * row's product zero or NaN), so signs are moved with bit operations instead of multiplications
- * by cl_sign() -- same bits, see the record's description. */
-template <int D>
-__device__ __forceinline__ bool ldsp_layer_row(float *P, ldpc_const_i32 pk, int z, int r, const uint4 old, uint4 *out)
-{
-    if (__ballot((old.w & kLdspIrregular) != 0u) == 0ull) {
-        float q[D];
-        int col[D], ent[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k) ent[k] = pk[k];
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const uint32_t t = (uint32_t)r + (uint32_t)(ent[k] & 0xffff);
-            const uint32_t tw = t - (uint32_t)z;                    /* wraps to a huge value when t < z */
-            col[k] = (ent[k] >> 16) * z + (int)(t < tw ? t : tw);
-        }
-        const int obind = (int)(old.w >> 16) & 31;
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const uint32_t sel = (k == obind) ? old.y : old.x;
-            const uint32_t sgn = ((k < 16 ? old.z : old.w) << (31 - (k & 15) * 2)) & 0x80000000u;
-            q[k] = P[col[k]] - __uint_as_float(sel ^ sgn);
-        }
-        float prod = 1.0f, b = 1000.0f, c = 1001.0f;
-        int bind = 31;
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            prod *= q[k];
-            const float mag = __builtin_fabsf(q[k]);
-            const bool le = mag <= b;
-            const float cm = mag <= c ? mag : c;                    /* no NaN on this path */
-            c = le ? b : cm;
-            b = le ? mag : b;
-            bind = le ? k : bind;
-        }
-        const uint32_t pb = __float_as_uint(prod);
-        if (__ballot(!ldsp_regular(pb)) == 0ull) {
-            const uint32_t ps = pb & 0x80000000u;                   /* cl_sign(prod) = +-1 */
-            const uint32_t ab = __float_as_uint(b) | ps, ac = __float_as_uint(c) | ps;
-            uint32_t lo = 0, hi = 0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                const uint32_t qb = __float_as_uint(q[k]);
-                const uint32_t sel = (k == bind) ? ac : ab;
-                P[col[k]] = q[k] + __uint_as_float(sel ^ (qb & 0x80000000u));
-                if (k < 16) lo |= (qb >> 31) << (k * 2);
-                else hi |= (qb >> 31) << ((k - 16) * 2);
-            }
-            hi |= (uint32_t)bind << 16;
-            *out = uint4{ab, ac, lo, hi};
-            return true;
-        }
-    }
-    return false;                                                   /* wave-uniform: P is untouched */
-}
-
-/* parities of the hard decisions P < 0 of the wave's rows, as a lane mask */
-template <int D>
-__device__ __forceinline__ uint64_t ldsp_row_parity(const float *P, ldpc_const_i32 pk, int z, int r)
-{
-    float v[D];
-    int ent[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) ent[k] = pk[k];
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        const uint32_t t = (uint32_t)r + (uint32_t)(ent[k] & 0xffff);
-        const uint32_t tw = t - (uint32_t)z;
-        v[k] = P[(ent[k] >> 16) * z + (int)(t < tw ? t : tw)];
-    }
-    uint64_t par = 0;
-#pragma unroll
-    for (int k = 0; k < D; ++k) par ^= __ballot(v[k] < 0.0f);
-    return par;
-}
-
-/* message k of a record (taps) */
-__device__ __forceinline__ float ldsp_message(const uint4 rec, int k)
-{
-    return __uint_as_float(ldsp_old_message(rec, k));
-}
-
-/* the row width is uniform over a layer: one switch per layer step picks the exact-width code */
-#define LDPC_LDSP_WIDTHS(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) \
-    X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
-
-template <int MAXW>
-__global__ __launch_bounds__(64 * MAXW) void layered_ldsp_kernel(const FusedArgs a, uint4 *__restrict__ recs_all)
-{
-    extern __shared__ float lds[];
-    float *P = lds;
-    const int r = (int)threadIdx.x, LANES = (int)blockDim.x;
-    const int z = a.z;
-    const bool row = r < z;
-    uint4 *recs = recs_all + (size_t)blockIdx.x * ((size_t)a.layers * z) + r;   /* [layer][z], mine: + r */
-    const ldpc_const_i32 lptr = as_constant(a.layer_ptr), pack = as_constant(a.ent_pack);
-    for (int64_t frame = blockIdx.x; frame < a.frames; frame += gridDim.x) {
-        const float *y = a.llr + (size_t)frame * a.N;
-        for (int n = r; n < a.N; n += LANES) P[n] = y[n];
-        __syncthreads();
-        int time = 0;
-        bool clean = false;
-        uint4 cur = uint4{0u, 0u, 0u, 0u};                         /* iteration 0: R = 0 (ab = ac = +0, signs +1) */
-        while (true) {
-            for (int l = 0; l < a.layers; ++l) {
-                /* the next layer step's record (wrapping into the next iteration), requested before
-                 * this step's work; with a single layer it is this step's own output */
-                const int ln = l + 1 < a.layers ? l + 1 : 0;
-                uint4 nxt = uint4{0u, 0u, 0u, 0u};
-                if (row && (time > 0 || ln == 0) && a.layers > 1) nxt = recs[(size_t)ln * z];
-                const int d = lptr[l + 1] - lptr[l];
-                const ldpc_const_i32 pk = pack + (size_t)l * a.pack_w;
-                if (row) {
-                    uint4 rec;
-                    bool done = false;
-                    switch (d) {
-#define LDPC_LDSP_CASE(D) case D: done = ldsp_layer_row<D>(P, pk, z, r, cur, &rec); break;
-                        LDPC_LDSP_WIDTHS(LDPC_LDSP_CASE)
-#undef LDPC_LDSP_CASE
-                    default: break;                                /* not reached: the plan admits d <= 24 only */
-                    }
-                    if (!done) rec = ldsp_layer_row_any(P, pk, d, z, r, cur);
-                    recs[(size_t)l * z] = rec;
-                    if (a.layers == 1) nxt = rec;
-                }
-                lds_barrier();
-                cur = nxt;
-            }
-            /* syndrome of the hard decisions: every round when a clean frame stops early, else only
-             * after the last one (its only use then is the frame's converged flag) */
-            ++time;
-            int any_bad = 1;
-            if (a.early_term || time == a.rounds) {
-                uint64_t bad = 0;
-                if (row) {
-                    for (int l = 0; l < a.layers; ++l) {
-                        const int d = lptr[l + 1] - lptr[l];
-                        const ldpc_const_i32 pk = pack + (size_t)l * a.pack_w;
-                        switch (d) {
-#define LDPC_LDSP_CASE(D) case D: bad |= ldsp_row_parity<D>(P, pk, z, r); break;
-                            LDPC_LDSP_WIDTHS(LDPC_LDSP_CASE)
-#undef LDPC_LDSP_CASE
-                        default: break;
-                        }
-                    }
-                }
-                any_bad = __syncthreads_or(bad != 0ull);
-            }
-            clean = !any_bad;
-            if ((clean && a.early_term) || time == a.rounds) break;
-        }
-        const int64_t base = frame * (int64_t)a.K / 8;
-        for (int j = r; j < a.K / 8; j += LANES) {
-            unsigned byte = 0;
-#pragma unroll
-            for (int bit = 0; bit < 8; ++bit) byte |= (P[j * 8 + bit] < 0.0f ? 1u : 0u) << bit;
-            if (base + j < a.out_bytes) a.out[base + j] = (uint8_t)byte;
-        }
-        if (a.dump_p)
-            for (int n = r; n < a.N; n += LANES) a.dump_p[(size_t)frame * a.N + n] = P[n];
-        if (a.dump_r && row) {
-            for (int l = 0; l < a.layers; ++l) {
-                const int d = a.layer_ptr[l + 1] - a.layer_ptr[l], e0 = a.layer_e0[l];
-                const uint4 rec = recs[(size_t)l * z];
-                for (int k = 0; k < d; ++k) a.dump_r[(size_t)frame * a.E + e0 + r * d + k] = ldsp_message(rec, k);
-            }
-        }
-        if (r == 0) {
-            const int it = clean ? time : a.max_iter;
-            if (a.iters) a.iters[frame] = it;
-            if (a.conv) a.conv[frame] = clean ? 1 : 0;
-            atomicMax(&a.summary[0], it);
-            if (clean) atomicAdd(&a.summary[1], 1);
-        }
-        __syncthreads();                                           /* P is refilled for the next frame */
-    }
-}
-
 /* ---------------------------------------------------------------- host side */
 
 struct FusedPlan {
@@ -1009,19 +732,13 @@ struct FusedPlan {
     size_t lds_sp = 0;
     int64_t dump_frames = 0;
     size_t lds_per_frame = 0;
-    /* layered_ldsp_kernel: posterior in LDS, check records in cache */
-    bool eligible_ldsp = false;
-    void *recs = nullptr;
-    int32_t ldsp_grid = 0, ldsp_block = 0, ldsp_maxw = 0;
-    size_t lds_ldsp = 0;
 };
 
 inline void fused_plan_destroy(FusedPlan *pl)
 {
     for (void *p : {(void *)pl->layer_ptr, (void *)pl->ent_bc, (void *)pl->ent_sh, (void *)pl->layer_e0,
                     (void *)pl->bcol_ptr, (void *)pl->bcol_e0, (void *)pl->bcol_sh, (void *)pl->ent_pack,
-                    (void *)pl->dump_p, (void *)pl->dump_r, (void *)pl->conv, (void *)pl->dump_q, (void *)pl->dump_b,
-                    pl->recs})
+                    (void *)pl->dump_p, (void *)pl->dump_r, (void *)pl->conv, (void *)pl->dump_q, (void *)pl->dump_b})
         if (p) (void)hipFree(p);
     *pl = FusedPlan();
 }
@@ -1063,7 +780,6 @@ inline bool fused_detect_qc(int32_t M, int32_t N, const std::vector<int32_t> &ro
 }
 
 constexpr size_t kFusedMaxLdsPerFrame = 48 * 1024;   /* >= 3 frames per CU (160 KB LDS) */
-constexpr size_t kLdspMaxLds = 160 * 1024;           /* layered_ldsp_kernel: one frame's posteriors */
 
 inline hipError_t fused_plan_create(FusedPlan *pl, int32_t M, int32_t N, int64_t E,
                                     const std::vector<int32_t> &row_ptr, const std::vector<int32_t> &cols,
@@ -1071,10 +787,7 @@ inline hipError_t fused_plan_create(FusedPlan *pl, int32_t M, int32_t N, int64_t
 {
     std::vector<int32_t> lp, bc, sh, e0;
     pl->eligible = false;
-    pl->eligible_ldsp = false;
-    const bool small = z <= 256 && (size_t)(N + E) * 4 <= kFusedMaxLdsPerFrame;
-    const bool mid = z <= 1024 && (size_t)N * 4 <= kLdspMaxLds;
-    if (!small && !mid) return hipSuccess;
+    if (z > 256 || (size_t)(N + E) * 4 > kFusedMaxLdsPerFrame) return hipSuccess;
     if (!fused_detect_qc(M, N, row_ptr, cols, z, lp, bc, sh, e0)) return hipSuccess;
     pl->z = z; pl->layers = M / z; pl->N = N; pl->E = (int32_t)E; pl->M = M;
     pl->max_deg = 0;
@@ -1118,39 +831,9 @@ inline hipError_t fused_plan_create(FusedPlan *pl, int32_t M, int32_t N, int64_t
     pl->max_col_deg = 0;
     for (int b = 0; b < nb; ++b) pl->max_col_deg = std::max(pl->max_col_deg, cp[b + 1] - cp[b]);
     pl->lds_sp = (size_t)(N + 2 * E) * 4 + (((size_t)N + 3) & ~(size_t)3);
-    pl->eligible_sp = small && pl->max_deg <= 24 && pl->max_col_deg <= 8 && pl->lds_sp <= kFusedMaxLdsPerFrame;
-    pl->eligible = small;
-    pl->eligible_ldsp = mid && pl->max_deg <= 24;
+    pl->eligible_sp = pl->max_deg <= 24 && pl->max_col_deg <= 8 && pl->lds_sp <= kFusedMaxLdsPerFrame;
+    pl->eligible = true;
     return hipSuccess;
-}
-
-typedef void (*LdspKernel)(const FusedArgs, uint4 *);
-
-inline LdspKernel ldsp_kernel_for(int maxw)
-{
-    return maxw == 4 ? layered_ldsp_kernel<4> : maxw == 8 ? layered_ldsp_kernel<8> : layered_ldsp_kernel<16>;
-}
-
-/* Size the persistent grid (as many workgroups as the chip holds at once, at most one per frame)
- * and allocate its record rings. */
-inline hipError_t ldsp_prepare(FusedPlan *pl, int64_t max_batch, int device)
-{
-    if (!pl->eligible_ldsp) return hipErrorInvalidValue;
-    const int mw = (pl->z + 63) / 64;
-    pl->ldsp_maxw = mw <= 4 ? 4 : mw <= 8 ? 8 : 16;
-    pl->ldsp_block = 64 * mw;
-    pl->lds_ldsp = (size_t)pl->N * sizeof(float);
-    LdspKernel k = ldsp_kernel_for(pl->ldsp_maxw);
-    hipError_t e;
-    if ((e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_ldsp))) return e;
-    int per_cu = 0, cus = 0;
-    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, pl->ldsp_block, pl->lds_ldsp))) return e;
-    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device))) return e;
-    if (per_cu < 1 || cus < 1) return hipErrorInvalidValue;
-    if (const char *t = getenv("LDPC_TUNE_LDSP_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(t)));
-    pl->ldsp_grid = (int32_t)std::min<int64_t>(max_batch, (int64_t)per_cu * cus);
-    if (const char *t = getenv("LDPC_TUNE_LDSP_GRID")) pl->ldsp_grid = std::max(1, std::min(pl->ldsp_grid, atoi(t)));
-    return hipMalloc(&pl->recs, (size_t)pl->ldsp_grid * pl->M * sizeof(uint4));
 }
 
 struct FusedRun {
@@ -1166,9 +849,11 @@ struct FusedRun {
     float llr_scale;
 };
 
-inline hipError_t fused_dump_buffers(FusedPlan *pl, const FusedRun &r)
+inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int32_t *launched)
 {
     hipError_t e;
+    if ((e = hipMemsetAsync(r.summary, 0, 2 * sizeof(int32_t), s))) return e;
+    const int rounds = r.tap_iter ? (r.tap_iter < r.max_iter ? r.tap_iter : r.max_iter) : r.max_iter;
     if (r.tap_iter && pl->dump_frames < r.frames) {
         for (void *p : {(void *)pl->dump_p, (void *)pl->dump_r, (void *)pl->dump_q, (void *)pl->dump_b})
             if (p) (void)hipFree(p);
@@ -1180,35 +865,6 @@ inline hipError_t fused_dump_buffers(FusedPlan *pl, const FusedRun &r)
         if ((e = hipMalloc((void **)&pl->dump_b, (size_t)r.frames * pl->N))) return e;
         pl->dump_frames = r.frames;
     }
-    return hipSuccess;
-}
-
-/* layered_ldsp_kernel launch: one persistent grid for the whole batch */
-inline hipError_t ldsp_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int32_t *launched)
-{
-    hipError_t e;
-    if ((e = hipMemsetAsync(r.summary, 0, 2 * sizeof(int32_t), s))) return e;
-    const int rounds = r.tap_iter ? (r.tap_iter < r.max_iter ? r.tap_iter : r.max_iter) : r.max_iter;
-    if ((e = fused_dump_buffers(pl, r))) return e;
-    FusedArgs a{r.llr_dev, r.out_dev, r.iters_dev, r.summary, r.tap_iter ? pl->dump_p : nullptr,
-                r.tap_iter ? pl->dump_r : nullptr, nullptr, nullptr, nullptr, r.llr_scale, pl->layer_ptr,
-                pl->ent_bc, pl->ent_sh, pl->layer_e0, pl->ent_pack, pl->pack_w, pl->bcol_ptr, pl->bcol_e0,
-                pl->bcol_sh, r.frames, r.out_dev ? r.out_bytes : 0, pl->N, pl->E, r.K, pl->z, pl->layers,
-                r.max_iter, rounds, r.early_term};
-    const unsigned grid = (unsigned)std::min<int64_t>(r.frames, pl->ldsp_grid);
-    LdspKernel k = ldsp_kernel_for(pl->ldsp_maxw);
-    if (!k || !pl->recs || grid == 0) return hipErrorInvalidValue;
-    k<<<grid, pl->ldsp_block, pl->lds_ldsp, s>>>(a, (uint4 *)pl->recs);
-    *launched = rounds;
-    return hipGetLastError();
-}
-
-inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int32_t *launched)
-{
-    hipError_t e;
-    if ((e = hipMemsetAsync(r.summary, 0, 2 * sizeof(int32_t), s))) return e;
-    const int rounds = r.tap_iter ? (r.tap_iter < r.max_iter ? r.tap_iter : r.max_iter) : r.max_iter;
-    if ((e = fused_dump_buffers(pl, r))) return e;
     FusedArgs a{r.llr_dev, r.out_dev, r.iters_dev, r.summary, r.tap_iter ? pl->dump_p : nullptr,
                 r.tap_iter ? pl->dump_r : nullptr, nullptr, r.tap_iter ? pl->dump_q : nullptr,
                 r.tap_iter ? pl->dump_b : nullptr, r.llr_scale, pl->layer_ptr, pl->ent_bc, pl->ent_sh,

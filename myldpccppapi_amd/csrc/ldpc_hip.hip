@@ -33,6 +33,7 @@
 #include "flood_kernels.hpp"
 #include "layered_kernels.hpp"
 #include "fused_kernels.hpp"
+#include "ldsp_kernels.hpp"
 
 namespace {
 
@@ -203,7 +204,8 @@ struct ldpc_decoder {
     ldpc::LayeredPlan layered;          /* LDPC_ALGO_LAYERED, streaming (one launch per layer) */
     ldpc::FusedPlan fused;              /* LDPC_ALGO_LAYERED, short QC codes: whole decode in LDS */
     bool use_fused = false;
-    bool use_ldsp = false;              /* layered: posterior in LDS, check records in cache */
+    ldpc::LdspPlan ldsp;                /* LDPC_ALGO_LAYERED, mid-size QC codes: posterior in LDS, check records in cache */
+    bool use_ldsp = false;
 
     /* staging for the host-buffer entry point: two slots, so the H2D copy of group k+1
      * (copy_stream) overlaps the decode of group k (stream) */
@@ -715,14 +717,13 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
         if (!(fe && atoi(fe) == 0) && (cfg->pack_mode == LDPC_PACK_BYTES || cfg->K % 8 == 0)) {
             HIP_TRY(ldpc::fused_plan_create(&d->fused, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows));
             d->use_fused = d->fused.eligible;
-            /* larger QC codes whose posteriors still fit in LDS: layered_ldsp_kernel
+            /* larger QC codes whose multi-layer posteriors still fit in LDS: layered_ldsp_kernel
              * (LDPC_TUNE_LDSP=0 keeps the streaming kernels, =1 prefers it over the fully fused one) */
             const char *le = getenv("LDPC_TUNE_LDSP");
-            if (d->fused.eligible_ldsp && cfg->msg_dtype == LDPC_MSG_F32 &&
-                (le ? atoi(le) != 0 : !d->use_fused)) {
-                HIP_TRY(ldpc::ldsp_prepare(&d->fused, cfg->max_batch, cfg->device));
-                d->use_fused = true;
-                d->use_ldsp = true;
+            if (le ? atoi(le) != 0 : !d->use_fused) {
+                HIP_TRY(ldpc::ldsp_plan_create(&d->ldsp, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows,
+                                               cfg->K, cfg->max_batch, cfg->device));
+                if (d->ldsp.eligible) d->use_fused = d->use_ldsp = true;
             }
         }
         /* the streaming plan (and its P / R arrays in HBM) only when no LDS-resident kernel applies;
@@ -765,6 +766,7 @@ int ldpc_decoder_destroy(ldpc_decoder *d)
     (void)hipDeviceSynchronize();
     ldpc::layered_plan_destroy(&d->layered);
     ldpc::fused_plan_destroy(&d->fused);
+    ldpc::ldsp_plan_destroy(&d->ldsp);
     delete d;
     return LDPC_OK;
 }
@@ -796,7 +798,7 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
                            d->cfg.llr_scale};
         hipError_t e = span_begin(d, s, 2, 0, (int64_t)frames * (4 * d->N + d->cfg.K / 8));
         if (e == hipSuccess)
-            e = d->use_ldsp ? ldpc::ldsp_run(&d->fused, run, s, &d->last_iterations)
+            e = d->use_ldsp ? ldpc::ldsp_run(&d->ldsp, run, s, &d->last_iterations)
                             : ldpc::fused_run(&d->fused, run, s, &d->last_iterations);
         if (e == hipSuccess) e = span_end(d, s);
         rc = (e == hipSuccess) ? LDPC_OK : fail(LDPC_ERR_HIP, "fused decode: %s", hipGetErrorString(e));
@@ -984,6 +986,10 @@ int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t ca
             out[k].phase = sp.kind == 4 ? 0 : sp.kind;      /* both are the check phase */
             out[k].degree = sp.degree;
             if (sp.kind == 3) snprintf(out[k].name, sizeof out[k].name, "other");
+            else if (d->use_fused)      /* whole decode in one launch; bytes = channel values in + packed bits out */
+                snprintf(out[k].name, sizeof out[k].name, "%s", d->use_ldsp ? "layered_ldsp_kernel"
+                         : d->cfg.algo == LDPC_ALGO_SP ? "fused_sp_kernel"
+                         : d->cfg.algo == LDPC_ALGO_LAYERED ? "fused_layered_kernel" : "fused_flood_kernel");
             else snprintf(out[k].name, sizeof out[k].name, "%s<%s,%d,%d>", phase_name[sp.kind],
                           algo_name[d->cfg.algo], sp.degree, d->V);
         }
@@ -1026,11 +1032,13 @@ int ldpc_decoder_dump(ldpc_decoder *d, int32_t which, float *host_out, int64_t c
         return LDPC_OK;
     }
     if (d->use_fused) {
-        const float *src = which == 0 ? d->fused.dump_r : (which == 2 ? d->fused.dump_p : nullptr);
+        const float *dump_r = d->use_ldsp ? d->ldsp.dump_r : d->fused.dump_r;
+        const float *dump_p = d->use_ldsp ? d->ldsp.dump_p : d->fused.dump_p;
+        const float *src = which == 0 ? dump_r : (which == 2 ? dump_p : nullptr);
         const int64_t per = which == 0 ? d->E : d->N;
         if (which == 3) {           /* hard bits = P < 0 */
-            if (!d->fused.dump_p || count != frames * d->N) return fail(LDPC_ERR_ARG, "fused dump needs set_tap() and count = frames*N");
-            HIP_TRY(hipMemcpy(host_out, d->fused.dump_p, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+            if (!dump_p || count != frames * d->N) return fail(LDPC_ERR_ARG, "fused dump needs set_tap() and count = frames*N");
+            HIP_TRY(hipMemcpy(host_out, dump_p, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
             const bool notpos = d->cfg.algo == LDPC_ALGO_MS;      /* MS chain: bit = !(p > 0) */
             for (int64_t i = 0; i < count; ++i)
                 host_out[i] = (notpos ? !(host_out[i] > 0.0f) : (host_out[i] < 0.0f)) ? 1.0f : 0.0f;

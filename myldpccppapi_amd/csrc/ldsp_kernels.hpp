@@ -1,0 +1,512 @@
+/*
+ * ldsp_kernels.hpp -- layered min-sum (the schedule of decodeOnceTDMP, decodeCL.c:307-426) for
+ * quasi-cyclic codes that are too large for the LDS-resident kernels of fused_kernels.hpp and
+ * for which one launch per layer over HBM (layered_kernels.hpp) is the wrong design as well:
+ * 5G-NR BG1 at Z = 384 (N = 26112, E = 121344, 46 layers) is the case it was written for.
+ *
+ * Data placement, per frame (one workgroup = one frame at a time, lanes = the z rows of a layer):
+ *   - posteriors of the block columns met by two or more layers live in LDS ([slot][z] floats,
+ *     read and written at consecutive addresses: column = slot*z + (row + shift) mod z);
+ *   - a block column met by ONE layer only (the 42 extension-parity columns of BG1) is touched
+ *     by exactly one row per iteration, so its posterior travels with that row's record instead
+ *     of occupying LDS: BG1 Z = 384 needs 26 * 384 * 4 B = 40 KB instead of 104 KB and four
+ *     frames share a CU's 160 KB;
+ *   - the check-to-variable messages are not stored as E floats.  A min-sum row sends two
+ *     magnitudes only, R_k = cl_sign(q_k) * (k == argmin ? ac : ab), so the row's state is the
+ *     16-byte record
+ *         x = |ab|   y = |ac|   z = sign bits of R_0..R_d-1 | argmin << 24 | irregular << 29
+ *         w = posterior of the row's single-layer column (if it has one)
+ *     from which the next iteration rebuilds every R_k bit for bit (see ldsp_old_message).
+ *     Row r of a layer is always lane r of the same workgroup: a record is read and written by
+ *     one thread only, as one 16-byte load and store per row and iteration, requested one layer
+ *     step ahead.  Workgroups are persistent and walk over the frames, so the record rings
+ *     (M * 16 B per resident workgroup) stay in L2 / Infinity Cache: HBM sees the channel values
+ *     once and the packed bits once.
+ * Arithmetic: the operations of layer_kernel / the oracle in the same order; where every q of a
+ * wave's rows is a regular number (not zero, not NaN, product not underflowed) the sign algebra
+ * is done on the bit patterns -- identical results, a third of the instructions; otherwise the
+ * wave takes ldsp_row_any, which performs the reference's operations one by one.
+ */
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "fused_kernels.hpp"
+
+namespace ldpc {
+
+constexpr int kLdspMaxDeg = 24;
+constexpr uint32_t kLdspIrregular = 1u << 29;
+constexpr size_t kLdspMaxLds = 160 * 1024 - 512;     /* one workgroup's dynamic LDS */
+
+struct LdspArgs {
+    const float *__restrict__ llr;        /* [frames][N] */
+    uint8_t *__restrict__ out;            /* packed bytes, toChar layout */
+    int32_t *__restrict__ iters;          /* [frames] or nullptr */
+    int32_t *__restrict__ summary;        /* [2]: max iters, converged frames */
+    float *__restrict__ dump_p;           /* [frames][N] or nullptr (taps) */
+    float *__restrict__ dump_r;           /* [frames][E] reference edge order, or nullptr */
+    uint4 *__restrict__ recs;             /* [grid][layers*z] check records */
+    uint32_t *__restrict__ zf;            /* [grid][layers*z] "message is a zero" bits of irregular records */
+    const int32_t *__restrict__ hdr;      /* [layers][4]: LDS entries, has external column, its first index, its shift */
+    const int32_t *__restrict__ pack;     /* [layers][2][24]: byte offset of the entry's LDS column (slot*z*4), then
+                                             its shift: ready-made operands, no scalar arithmetic per edge */
+    const int32_t *__restrict__ col_slot; /* [N/z]: LDS slot of the block column, -1 = travels with a record */
+    const int32_t *__restrict__ layer_e0; /* [layers]: edge id of the layer's first edge */
+    int64_t frames, out_bytes;
+    int32_t N, E, K, z, layers, nb, lds_cols, max_iter, rounds, early_term;
+};
+
+/* The kernel stores to global memory inside its layer loop, so the compiler may not assume that
+ * the code tables are unchanged and would fetch them with per-lane vector loads and a memory
+ * round trip per layer step; read through the constant address space they stay scalar loads
+ * (the tables are written once, by the host, before any launch). */
+typedef const int32_t __attribute__((address_space(4))) *ldpc_const_i32;
+__device__ __forceinline__ ldpc_const_i32 as_constant(const int32_t *p) { return (ldpc_const_i32)(uintptr_t)p; }
+
+/* Workgroup barrier that orders LDS traffic only: the global loads / stores of this kernel are
+ * private to their thread, and waiting for them (as __syncthreads() does) would put a memory
+ * round trip into every layer step. */
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ bool ldsp_regular(uint32_t bits)      /* finite non-zero, or infinite */
+{
+    return ((bits & 0x7fffffffu) - 1u) < 0x7f800000u;
+}
+
+__device__ __forceinline__ int ldsp_wrap(int r, int shift, int z)   /* (r + shift) mod z, r and shift < z */
+{
+    const uint32_t t = (uint32_t)r + (uint32_t)shift;
+    const uint32_t tw = t - (uint32_t)z;                            /* wraps to a huge value when t < z */
+    return (int)(t < tw ? t : tw);
+}
+
+__device__ __forceinline__ float *ldsp_at(float *P, int column_bytes, int t)
+{
+    return reinterpret_cast<float *>(reinterpret_cast<char *>(P) + column_bytes + t * 4);
+}
+
+/* Message k of a d-entry record: cl_sign(q) is +-1 for a regular q, so R = +-sel; it is +-0 for
+ * q = +-0 and +0 for NaN, so R is a zero then (zf bit).  sel = sa*min is finite always. */
+__device__ __forceinline__ uint32_t ldsp_old_message(const uint4 rec, uint32_t zf, int k, int d)
+{
+    const uint32_t mag = ((zf >> k) & 1u) ? 0u : ((k == (int)((rec.z >> 24) & 31u)) ? rec.y : rec.x);
+    return mag | (((rec.z >> (d - 1 - k)) & 1u) << 31);
+}
+
+/* Any input: the reference's operations one by one (decodeCL.c:345-383) with run-time loops, q
+ * parked in P between the two passes as the reference does. */
+__device__ __forceinline__ uint4 ldsp_row_any(float *P, ldpc_const_i32 pk, int dl, int ext, int z, int r,
+                                              const uint4 old, uint32_t *zfp, uint32_t *par)
+{
+    *par = 0;
+    const int d = dl + ext;
+    const uint32_t ozf = (old.z & kLdspIrregular) ? *zfp : 0u;
+    float prod = 1.0f, b = 1000.0f, c = 1001.0f, qext = 0.0f;
+    int bind = 31;
+    for (int k = 0; k < d; ++k) {
+        const float rold = __uint_as_float(ldsp_old_message(old, ozf, k, d));
+        float q;
+        if (k < dl) {
+            float *p = ldsp_at(P, pk[k], ldsp_wrap(r, pk[kLdspMaxDeg + k], z));
+            q = *p - rold;
+            *p = q;
+        } else {
+            q = __uint_as_float(old.w) - rold;
+            qext = q;
+        }
+        prod *= q;
+        const float mag = __builtin_fabsf(q);
+        if (mag <= b) { c = b; b = mag; bind = k; }
+        else if (mag > b && mag <= c) { c = mag; }
+    }
+    const float sa = cl_sign(prod);
+    const float ab = sa * b, ac = sa * c;
+    const uint32_t mab = __float_as_uint(ab) & 0x7fffffffu, mac = __float_as_uint(ac) & 0x7fffffffu;
+    uint32_t signs = 0, zf = 0, pext = 0;
+    for (int k = 0; k < d; ++k) {
+        float *p = P;
+        float q = qext;
+        if (k < dl) {
+            p = ldsp_at(P, pk[k], ldsp_wrap(r, pk[kLdspMaxDeg + k], z));
+            q = *p;
+        }
+        const float rn = cl_sign(q) * ((k == bind) ? ac : ab);
+        const float pn = q + rn;
+        if (k < dl) *p = pn;
+        else pext = __float_as_uint(pn);
+        if (pn < 0.0f) *par ^= 1u;
+        const uint32_t rb = __float_as_uint(rn);
+        signs = (signs << 1) | (rb >> 31);
+        if ((rb & 0x7fffffffu) != ((k == bind) ? mac : mab)) zf |= 1u << k;   /* then it is a zero */
+    }
+    uint32_t word = signs | ((uint32_t)bind << 24);
+    if (zf) {
+        word |= kLdspIrregular;
+        *zfp = zf;
+    }
+    return uint4{mab, mac, word, pext};
+}
+
+/* Exact row width (DL entries in LDS + EXT external), straight-line code.  Returns false,
+ * wave-uniformly and with P untouched, when some row of the wave needs ldsp_row_any. */
+template <int DL, int EXT>
+__device__ __forceinline__ bool ldsp_row(float *P, ldpc_const_i32 pk, int z, int r, const uint4 old, uint4 *out,
+                                         uint32_t *par)
+{
+    constexpr int D = DL + EXT;
+    constexpr int DLA = DL > 0 ? DL : 1;
+    if (__ballot((old.z & kLdspIrregular) != 0u) != 0ull) return false;
+    float q[D];
+    float *at[DLA];
+#pragma unroll
+    for (int k = 0; k < DL; ++k) at[k] = ldsp_at(P, pk[k], ldsp_wrap(r, pk[kLdspMaxDeg + k], z));
+    const int obind = (int)((old.z >> 24) & 31u);
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const uint32_t sel = (k == obind) ? old.y : old.x;
+        const uint32_t rold = ((old.z << (31 - (D - 1 - k))) & 0x80000000u) | sel;
+        q[k] = (k < DL ? *at[k < DL ? k : 0] : __uint_as_float(old.w)) - __uint_as_float(rold);
+    }
+    float prod = 1.0f, b = 1000.0f, c = 1001.0f;
+    int bind = 31;                                                  /* none (all |q| > 1000) */
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        prod *= q[k];
+        const float mag = __builtin_fabsf(q[k]);
+        const bool le = mag <= b;
+        bind = le ? k : bind;
+        c = __builtin_amdgcn_fmed3f(b, mag, c);                     /* b <= c: the branches of decodeCL.c:359-365 */
+        b = __builtin_amdgcn_fmed3f(0.0f, mag, b);                  /* min(b, mag): both >= 0 */
+    }
+    const uint32_t pb = __float_as_uint(prod);
+    if (__ballot(!ldsp_regular(pb)) != 0ull) return false;
+    const uint32_t ps = pb & 0x80000000u;                           /* cl_sign(prod) = +-1 */
+    const uint32_t mb = __float_as_uint(b), mc = __float_as_uint(c);
+    uint32_t signs = 0, pext = 0, px = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const uint32_t sel = (k == bind) ? mc : mb;
+        const uint32_t rn = ((__float_as_uint(q[k]) ^ ps) & 0x80000000u) | sel;
+        const float pn = q[k] + __uint_as_float(rn);
+        if (k < DL) *at[k < DL ? k : 0] = pn;
+        else pext = __float_as_uint(pn);
+        signs = __builtin_amdgcn_alignbit(signs, rn, 31);           /* (signs << 1) | sign(rn) */
+        px ^= __float_as_uint(pn);                                  /* regular q, sel > 0: pn < 0 <=> sign bit */
+    }
+    *out = uint4{mb, mc, signs | ((uint32_t)bind << 24), pext};
+    *par = px >> 31;
+    return true;
+}
+
+/* parities of the hard decisions P < 0 over the LDS entries of the wave's rows, as a lane mask */
+template <int DL>
+__device__ __forceinline__ uint64_t ldsp_row_parity(const float *P, ldpc_const_i32 pk, int z, int r)
+{
+    constexpr int DLA = DL > 0 ? DL : 1;
+    float v[DLA];
+#pragma unroll
+    for (int k = 0; k < DL; ++k) v[k] = *ldsp_at(const_cast<float *>(P), pk[k], ldsp_wrap(r, pk[kLdspMaxDeg + k], z));
+    uint64_t par = 0;
+#pragma unroll
+    for (int k = 0; k < DL; ++k) par ^= __ballot(v[k] < 0.0f);
+    return par;
+}
+
+#define LDPC_LDSP_WIDTHS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) \
+    X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23)
+
+/* Register budget: at BG1 Z = 384 a workgroup is 6 waves and 40 KB of LDS; three workgroups per
+ * CU (18 waves, 4.5 per SIMD) already keep the vector ALUs as busy as four do, and 96 VGPRs
+ * hold the widest rows (19 + 1 entries) without spilling. */
+#ifndef LDPC_LDSP_WAVES_PER_EU
+#define LDPC_LDSP_WAVES_PER_EU 6
+#endif
+
+template <int MAXW>
+__global__ __launch_bounds__(64 * MAXW) __attribute__((amdgpu_waves_per_eu(LDPC_LDSP_WAVES_PER_EU)))
+void layered_ldsp_kernel(const LdspArgs a)
+{
+    extern __shared__ float lds[];
+    float *P = lds;                                                             /* [lds_cols][z] */
+    const int r = (int)threadIdx.x, LANES = (int)blockDim.x, MW = LANES >> 6, wave = r >> 6;
+    const int z = a.z;
+    uint64_t *extneg = reinterpret_cast<uint64_t *>(lds + (((size_t)a.lds_cols * z + 1) & ~(size_t)1));  /* [layers][MW] */
+    uint32_t *wg_flag = reinterpret_cast<uint32_t *>(extneg + (size_t)a.layers * MW);
+    const bool row = r < z;
+    const size_t ring = (size_t)blockIdx.x * ((size_t)a.layers * z) + r;        /* [layer][z], mine: + r */
+    uint4 *recs = a.recs + ring;
+    uint32_t *zfs = a.zf + ring;
+    const ldpc_const_i32 hdr = as_constant(a.hdr), pack = as_constant(a.pack), cslot = as_constant(a.col_slot);
+    /* OR over the workgroup through one LDS word (no static LDS: P sits at LDS address 0 and the
+     * table's byte offsets are final addresses) */
+    auto wg_any = [&](bool pred) {
+        if (r == 0) *wg_flag = 0u;
+        lds_barrier();
+        if (__ballot(pred) != 0ull && (r & 63) == 0) *wg_flag = 1u;
+        lds_barrier();
+        const uint32_t f = *wg_flag;
+        lds_barrier();                                             /* before the word is cleared again */
+        return f != 0u;
+    };
+    for (int64_t frame = blockIdx.x; frame < a.frames; frame += gridDim.x) {
+        const float *y = a.llr + (size_t)frame * a.N;
+        if (row) {
+            for (int bc = 0; bc < a.nb; ++bc) {
+                const int slot = cslot[bc];
+                if (slot >= 0) P[slot * z + r] = y[bc * z + r];
+            }
+            /* iteration 0: R = 0 (|ab| = |ac| = 0, signs +); an external column starts from its
+             * channel value.  Written to the ring so that every layer step finds its record there. */
+            for (int l = 0; l < a.layers; ++l) {
+                uint4 rec = uint4{0u, 0u, 0u, 0u};
+                if (hdr[l * 4 + 1]) rec.w = __float_as_uint(y[hdr[l * 4 + 2] + ldsp_wrap(r, hdr[l * 4 + 3], z)]);
+                recs[(size_t)l * z] = rec;
+            }
+        }
+        uint4 cur = uint4{0u, 0u, 0u, 0u};
+        if (row) cur = recs[0];
+        __syncthreads();
+        int time = 0;
+        bool clean = false;
+        while (true) {
+            uint32_t last_bad = 0;
+            for (int l = 0; l < a.layers; ++l) {
+                /* the next layer step's record (wrapping into the next iteration), requested before
+                 * this step's work; with a single layer it is this step's own output */
+                const int ln = l + 1 < a.layers ? l + 1 : 0;
+                uint4 nxt = uint4{0u, 0u, 0u, 0u};
+                if (row && a.layers > 1) nxt = recs[(size_t)ln * z];
+                const int dl = hdr[l * 4], ext = hdr[l * 4 + 1];
+                const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
+                if (row) {
+                    uint4 rec;
+                    uint32_t par = 0;                               /* parity of the row's hard decisions as it leaves them */
+                    bool done = false;
+                    if (ext) {
+                        switch (dl) {
+#define LDPC_LDSP_CASE(D) case D: done = ldsp_row<D, 1>(P, pk, z, r, cur, &rec, &par); break;
+                            LDPC_LDSP_WIDTHS(LDPC_LDSP_CASE)
+#undef LDPC_LDSP_CASE
+                        default: break;
+                        }
+                    } else {
+                        switch (dl) {
+#define LDPC_LDSP_CASE(D) case D + 1: done = ldsp_row<D + 1, 0>(P, pk, z, r, cur, &rec, &par); break;
+                            LDPC_LDSP_WIDTHS(LDPC_LDSP_CASE)
+#undef LDPC_LDSP_CASE
+                        default: break;
+                        }
+                    }
+                    if (!done) rec = ldsp_row_any(P, pk, dl, ext, z, r, cur, zfs + (size_t)l * z, &par);
+                    last_bad = par;
+                    /* the requested record has had this step's work to arrive: take it BEFORE the
+                     * store below is issued, or the wait for it would cover the store as well and
+                     * put a full memory round trip into every layer step */
+                    asm volatile("" : "+v"(nxt.x), "+v"(nxt.y), "+v"(nxt.z), "+v"(nxt.w) : : "memory");
+                    recs[(size_t)l * z] = rec;
+                    if (a.layers == 1) nxt = rec;
+                    if (ext) {                                      /* hard decision of the external column */
+                        const uint64_t neg = __ballot(__uint_as_float(rec.w) < 0.0f);
+                        if ((r & 63) == 0) extneg[l * MW + wave] = neg;
+                    }
+                }
+                lds_barrier();
+                cur = nxt;
+            }
+            /* syndrome of the hard decisions: every round when a clean frame stops early, else only
+             * after the last one (its only use then is the frame's converged flag) */
+            ++time;
+            int any_bad = 1;
+            /* the rows of the last layer leave their columns in the iteration's final state, so
+             * their parities are known already: only when all of them are even (hardly ever
+             * before the frame has converged) the other layers need to be looked at */
+            if ((a.early_term || time == a.rounds) && !wg_any(row && last_bad)) {
+                uint64_t bad = 0;
+                if (row) {
+                    for (int l = 0; l < a.layers; ++l) {
+                        const int dl = hdr[l * 4], ext = hdr[l * 4 + 1];
+                        const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
+                        uint64_t par = 0;
+                        switch (dl) {
+#define LDPC_LDSP_CASE(D) case D + 1: par = ldsp_row_parity<D + 1>(P, pk, z, r); break;
+                            LDPC_LDSP_WIDTHS(LDPC_LDSP_CASE)
+#undef LDPC_LDSP_CASE
+                        default: break;
+                        }
+                        if (ext) par ^= extneg[l * MW + wave];
+                        bad |= par;
+                    }
+                }
+                any_bad = wg_any(bad != 0ull) ? 1 : 0;
+            }
+            clean = !any_bad;
+            if ((clean && a.early_term) || time == a.rounds) break;
+        }
+        /* toChar (decodeCL.c:414-423): the information columns sit in LDS at slot = block column */
+        const int64_t base = frame * (int64_t)a.K / 8;
+        for (int j = r; j < a.K / 8; j += LANES) {
+            unsigned byte = 0;
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) byte |= (P[j * 8 + bit] < 0.0f ? 1u : 0u) << bit;
+            if (base + j < a.out_bytes) a.out[base + j] = (uint8_t)byte;
+        }
+        if (a.dump_p && row) {
+            for (int bc = 0; bc < a.nb; ++bc) {
+                const int slot = cslot[bc];
+                if (slot >= 0) a.dump_p[(size_t)frame * a.N + bc * z + r] = P[slot * z + r];
+            }
+            for (int l = 0; l < a.layers; ++l)
+                if (hdr[l * 4 + 1])
+                    a.dump_p[(size_t)frame * a.N + hdr[l * 4 + 2] + ldsp_wrap(r, hdr[l * 4 + 3], z)] =
+                        __uint_as_float(recs[(size_t)l * z].w);
+        }
+        if (a.dump_r && row) {
+            for (int l = 0; l < a.layers; ++l) {
+                const int d = hdr[l * 4] + hdr[l * 4 + 1], e0 = a.layer_e0[l];
+                const uint4 rec = recs[(size_t)l * z];
+                const uint32_t zf = (rec.z & kLdspIrregular) ? zfs[(size_t)l * z] : 0u;
+                for (int k = 0; k < d; ++k)
+                    a.dump_r[(size_t)frame * a.E + e0 + r * d + k] = __uint_as_float(ldsp_old_message(rec, zf, k, d));
+            }
+        }
+        if (r == 0) {
+            const int it = clean ? time : a.max_iter;
+            if (a.iters) a.iters[frame] = it;
+            atomicMax(&a.summary[0], it);
+            if (clean) atomicAdd(&a.summary[1], 1);
+        }
+        __syncthreads();                                           /* P is refilled for the next frame */
+    }
+}
+
+/* ---------------------------------------------------------------- host side */
+
+struct LdspPlan {
+    bool eligible = false;
+    int32_t z = 0, layers = 0, N = 0, E = 0, M = 0, nb = 0, lds_cols = 0, ext_cols = 0;
+    int32_t *hdr = nullptr, *pack = nullptr, *col_slot = nullptr, *layer_e0 = nullptr;   /* device */
+    uint4 *recs = nullptr;
+    uint32_t *zf = nullptr;
+    float *dump_p = nullptr, *dump_r = nullptr;
+    int64_t dump_frames = 0;
+    int32_t grid = 0, block = 0, maxw = 0, per_cu = 0;
+    size_t lds_bytes = 0;
+};
+
+inline void ldsp_plan_destroy(LdspPlan *pl)
+{
+    for (void *p : {(void *)pl->hdr, (void *)pl->pack, (void *)pl->col_slot, (void *)pl->layer_e0, (void *)pl->recs,
+                    (void *)pl->zf, (void *)pl->dump_p, (void *)pl->dump_r})
+        if (p) (void)hipFree(p);
+    *pl = LdspPlan();
+}
+
+typedef void (*LdspKernel)(const LdspArgs);
+inline LdspKernel ldsp_kernel_for(int maxw) { return maxw <= 8 ? layered_ldsp_kernel<8> : layered_ldsp_kernel<16>; }
+
+/* Detect the QC structure, decide which block columns travel with a record (met by one layer
+ * only, last entry of that layer's rows, not an information column), lay the others out in LDS,
+ * size the persistent grid and allocate its record rings.  eligible = false (and hipSuccess)
+ * when the code does not fit this kernel. */
+inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E, const std::vector<int32_t> &row_ptr,
+                                   const std::vector<int32_t> &cols, int32_t z, int32_t K, int64_t max_batch, int device)
+{
+    std::vector<int32_t> lp, bc, sh, e0;
+    pl->eligible = false;
+    if (z <= 0 || z > 1024 || !fused_detect_qc(M, N, row_ptr, cols, z, lp, bc, sh, e0)) return hipSuccess;
+    const int layers = M / z, nb = N / z;
+    int max_deg = 0;
+    for (int l = 0; l < layers; ++l) max_deg = std::max(max_deg, lp[l + 1] - lp[l]);
+    if (max_deg > kLdspMaxDeg) return hipSuccess;
+    std::vector<int32_t> deg(nb, 0);
+    for (int32_t b : bc) ++deg[b];
+    const char *ee = getenv("LDPC_TUNE_LDSP_EXT");
+    const bool allow_ext = !(ee && atoi(ee) == 0);
+    std::vector<int32_t> slot(nb, 0), hdr((size_t)layers * 4, 0), pack((size_t)layers * 2 * kLdspMaxDeg, 0);
+    std::vector<char> external(nb, 0);
+    int ext_cols = 0;
+    for (int l = 0; l < layers; ++l) {
+        const int last = bc[lp[l + 1] - 1];
+        if (allow_ext && deg[last] == 1 && (int64_t)last * z >= K) { external[last] = 1; ++ext_cols; }
+    }
+    int lds_cols = 0;
+    for (int b = 0; b < nb; ++b) slot[b] = external[b] ? -1 : lds_cols++;
+    for (int l = 0; l < layers; ++l) {
+        const int d = lp[l + 1] - lp[l], last = lp[l + 1] - 1;
+        const int ext = external[bc[last]] ? 1 : 0;
+        hdr[l * 4 + 0] = d - ext;
+        hdr[l * 4 + 1] = ext;
+        hdr[l * 4 + 2] = ext ? bc[last] * z : 0;
+        hdr[l * 4 + 3] = ext ? sh[last] : 0;
+        for (int k = 0; k < d - ext; ++k) {
+            pack[(size_t)l * 2 * kLdspMaxDeg + k] = slot[bc[lp[l] + k]] * z * 4;
+            pack[(size_t)l * 2 * kLdspMaxDeg + kLdspMaxDeg + k] = sh[lp[l] + k];
+        }
+    }
+    int mw = (z + 63) / 64;
+    if (const char *t = getenv("LDPC_TUNE_LDSP_WAVES")) mw = std::min(16, std::max(mw, atoi(t)));   /* idle waves appended */
+    const size_t lds_bytes = ((((size_t)lds_cols * z + 1) & ~(size_t)1)) * sizeof(float) + (size_t)layers * mw * sizeof(uint64_t) + 8;
+    if (lds_bytes > kLdspMaxLds || lds_cols >= 32768) return hipSuccess;
+    pl->z = z; pl->layers = layers; pl->N = N; pl->E = (int32_t)E; pl->M = M; pl->nb = nb;
+    pl->lds_cols = lds_cols; pl->ext_cols = ext_cols; pl->lds_bytes = lds_bytes;
+    pl->maxw = mw <= 8 ? 8 : 16;
+    pl->block = 64 * mw;
+    auto up = [](int32_t **dst, const std::vector<int32_t> &v) {
+        hipError_t e = hipMalloc((void **)dst, v.size() * sizeof(int32_t));
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*dst, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    };
+    hipError_t e;
+    if ((e = up(&pl->hdr, hdr)) || (e = up(&pl->pack, pack)) || (e = up(&pl->col_slot, slot)) || (e = up(&pl->layer_e0, e0)))
+        return e;
+    LdspKernel k = ldsp_kernel_for(pl->maxw);
+    if ((e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes))) return e;
+    int per_cu = 0, cus = 0;
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, pl->block, lds_bytes))) return e;
+    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device))) return e;
+    if (per_cu < 1 || cus < 1) return hipErrorInvalidValue;
+    if (const char *t = getenv("LDPC_TUNE_LDSP_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(t)));
+    pl->per_cu = per_cu;
+    pl->grid = (int32_t)std::min<int64_t>(std::max<int64_t>(max_batch, 1), (int64_t)per_cu * cus);
+    if (const char *t = getenv("LDPC_TUNE_LDSP_GRID")) pl->grid = std::max(1, std::min(pl->grid, atoi(t)));
+    if ((e = hipMalloc((void **)&pl->recs, (size_t)pl->grid * M * sizeof(uint4)))) return e;
+    if ((e = hipMalloc((void **)&pl->zf, (size_t)pl->grid * M * sizeof(uint32_t)))) return e;
+    pl->eligible = true;
+    return hipSuccess;
+}
+
+/* one persistent grid for the whole batch */
+inline hipError_t ldsp_run(LdspPlan *pl, const FusedRun &r, hipStream_t s, int32_t *launched)
+{
+    hipError_t e;
+    if ((e = hipMemsetAsync(r.summary, 0, 2 * sizeof(int32_t), s))) return e;
+    const int rounds = r.tap_iter ? (r.tap_iter < r.max_iter ? r.tap_iter : r.max_iter) : r.max_iter;
+    if (r.tap_iter && pl->dump_frames < r.frames) {
+        if (pl->dump_p) (void)hipFree(pl->dump_p);
+        if (pl->dump_r) (void)hipFree(pl->dump_r);
+        pl->dump_p = pl->dump_r = nullptr;
+        if ((e = hipMalloc((void **)&pl->dump_p, (size_t)r.frames * pl->N * sizeof(float)))) return e;
+        if ((e = hipMalloc((void **)&pl->dump_r, (size_t)r.frames * pl->E * sizeof(float)))) return e;
+        pl->dump_frames = r.frames;
+    }
+    LdspArgs a{r.llr_dev, r.out_dev, r.iters_dev, r.summary, r.tap_iter ? pl->dump_p : nullptr,
+               r.tap_iter ? pl->dump_r : nullptr, pl->recs, pl->zf, pl->hdr, pl->pack, pl->col_slot, pl->layer_e0,
+               r.frames, r.out_dev ? r.out_bytes : 0, pl->N, pl->E, r.K, pl->z, pl->layers, pl->nb, pl->lds_cols,
+               r.max_iter, rounds, r.early_term};
+    const unsigned grid = (unsigned)std::min<int64_t>(r.frames, pl->grid);
+    if (!pl->eligible || grid == 0) return hipErrorInvalidValue;
+    ldsp_kernel_for(pl->maxw)<<<grid, pl->block, pl->lds_bytes, s>>>(a);
+    *launched = rounds;
+    return hipGetLastError();
+}
+
+}  // namespace ldpc

@@ -263,6 +263,18 @@ def test_degenerate_channel_values(built, algo, monkeypatch):
         kb = K // 8
         assert np.array_equal(out.reshape(24, kb)[ok], want["out"].reshape(24, kb)[ok]), (algo, fused)
         assert np.array_equal(iters[ok], want["iters"][ok]), (algo, fused)
+        if algo == "layered":
+            # messages and posteriors after two iterations, bit patterns (signs of zeros included);
+            # only where the oracle has a NaN the payload is left open
+            tap = oracle.decode(og, y, algo, max_iter=15, layer_rows=z, tap_iter=2)
+            dec.set_tap(2)
+            dec.decode(y)
+            run = ok & (want["iters"] >= 2)
+            for which, name in ((0, "r"), (2, "post")):
+                got, ref = dec.dump(which, 24)[run], tap["taps"][name][run]
+                num = ~np.isnan(ref)
+                assert np.array_equal(got.view(np.uint32)[num], ref.view(np.uint32)[num]), (fused, name)
+                assert np.isnan(got[~num]).all(), (fused, name)
         dec.close()
 
 
