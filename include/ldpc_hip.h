@@ -175,6 +175,22 @@ int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t ca
 int ldpc_decoder_set_tap(ldpc_decoder *d, int32_t iter);
 int ldpc_decoder_dump(ldpc_decoder *d, int32_t which, float *host_out, int64_t count);
 
+/* ---- test channel and error count on the device: replace Coder::test / gaussian
+ *      (MyLdpc.cpp:1061-1105: BPSK, bit 0 -> +1.0, bit 1 -> -1.0, plus N(0, sd^2)) and the
+ *      comparison loop of Test.cpp:105-110, for data that never leaves HBM.
+ * ldpc_awgn_device: llr_dev[f*N + n] = (bits ? 1 - 2*bits[f*N + n] : +1) + sd * z(seed, first_frame + f, n)
+ *      for f < frames; bits_dev: one byte per code bit (0/1), NULL = the all-zero codeword.  z is
+ *      the counter-based standard normal of csrc/ldpc_channel.h (Philox4x32-10 + Box-Muller in
+ *      IEEE double; identical on host and device, any frame range reproducible anywhere), NOT
+ *      the reference's rand()-based gaussian().  Enqueued on `stream`, returns without waiting.
+ * ldpc_count_errors_device: compares two packed outputs of `frames` x `bytes_per_frame` bytes
+ *      (ref_dev NULL = all zero); blocks; errors[0] = differing bits, [1] = differing bytes (the
+ *      reference's ErrNum), [2] = frames with at least one difference. */
+int ldpc_awgn_device(float *llr_dev, int64_t frames, int32_t N, const uint8_t *bits_dev, float sd,
+                     uint64_t seed, int64_t first_frame, int32_t device, void *stream);
+int ldpc_count_errors_device(const uint8_t *out_dev, const uint8_t *ref_dev, int64_t frames,
+                             int64_t bytes_per_frame, int64_t errors[3], int32_t device, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

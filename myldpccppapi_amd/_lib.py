@@ -52,7 +52,7 @@ EXPORTS = (
     "ldpc_graph_destroy", "ldpc_graph_info", "ldpc_decoder_config_init", "ldpc_decoder_create",
     "ldpc_decoder_destroy", "ldpc_decode", "ldpc_decode_device", "ldpc_out_bytes",
     "ldpc_decoder_set_timing", "ldpc_decoder_stats", "ldpc_decoder_kernel_times", "ldpc_decoder_set_tap",
-    "ldpc_decoder_dump",
+    "ldpc_decoder_dump", "ldpc_awgn_device", "ldpc_count_errors_device",
 )
 
 
@@ -96,6 +96,9 @@ def load():
     L.ldpc_decoder_kernel_times.argtypes = [vp, ctypes.POINTER(KernelTime), ctypes.c_int32, i32p]
     L.ldpc_decoder_set_tap.argtypes = [vp, ctypes.c_int32]
     L.ldpc_decoder_dump.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int64]
+    L.ldpc_awgn_device.argtypes = [vp, ctypes.c_int64, ctypes.c_int32, vp, ctypes.c_float, ctypes.c_uint64,
+                                   ctypes.c_int64, ctypes.c_int32, vp]
+    L.ldpc_count_errors_device.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, i64p, ctypes.c_int32, vp]
     _lib = L
     return L
 

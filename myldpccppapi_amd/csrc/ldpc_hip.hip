@@ -34,6 +34,7 @@
 #include "layered_kernels.hpp"
 #include "fused_kernels.hpp"
 #include "ldsp_kernels.hpp"
+#include "channel_kernels.hpp"
 
 namespace {
 
@@ -1093,6 +1094,50 @@ int ldpc_decoder_dump(ldpc_decoder *d, int32_t which, float *host_out, int64_t c
         return LDPC_OK;
     }
     return fail(LDPC_ERR_ARG, "unknown `which` %d", which);
+}
+
+int ldpc_awgn_device(float *llr_dev, int64_t frames, int32_t N, const uint8_t *bits_dev, float sd,
+                     uint64_t seed, int64_t first_frame, int32_t device, void *stream)
+{
+    if (!llr_dev) return fail(LDPC_ERR_ARG, "llr_dev is NULL");
+    if (frames < 0 || N <= 0 || first_frame < 0) return fail(LDPC_ERR_ARG, "frames=%lld, N=%d, first_frame=%lld",
+                                                             (long long)frames, N, (long long)first_frame);
+    if (!(sd >= 0.0f)) return fail(LDPC_ERR_ARG, "sd must be >= 0");
+    if (frames == 0) return LDPC_OK;
+    HIP_TRY(hipSetDevice(device));
+    const int32_t groups = (N + 3) / 4;
+    const int64_t threads = frames * groups;
+    const int64_t blocks = (threads + 255) / 256;
+    if (blocks > 0x7fffffffLL) return fail(LDPC_ERR_ARG, "too many samples for one call");
+    ldpc::awgn_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(llr_dev, bits_dev, frames, N, groups, sd,
+                                                                         seed, first_frame);
+    HIP_TRY(hipGetLastError());
+    return LDPC_OK;
+}
+
+int ldpc_count_errors_device(const uint8_t *out_dev, const uint8_t *ref_dev, int64_t frames,
+                             int64_t bytes_per_frame, int64_t errors[3], int32_t device, void *stream)
+{
+    if (!out_dev || !errors) return fail(LDPC_ERR_ARG, "out_dev/errors is NULL");
+    if (frames < 0 || bytes_per_frame <= 0 || frames > 0x7fffffffLL) return fail(LDPC_ERR_ARG, "bad frames/bytes_per_frame");
+    errors[0] = errors[1] = errors[2] = 0;
+    if (frames == 0) return LDPC_OK;
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *totals = nullptr;
+    HIP_TRY(hipMalloc((void **)&totals, 3 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(totals, 0, 3 * sizeof(unsigned long long), s);
+    if (e == hipSuccess) {
+        ldpc::count_errors_kernel<<<(unsigned)frames, 256, 0, s>>>(out_dev, ref_dev, frames, bytes_per_frame, totals);
+        e = hipGetLastError();
+    }
+    unsigned long long h[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(h, totals, sizeof h, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(totals);
+    if (e != hipSuccess) return fail(LDPC_ERR_HIP, "count_errors: %s", hipGetErrorString(e));
+    for (int i = 0; i < 3; ++i) errors[i] = (int64_t)h[i];
+    return LDPC_OK;
 }
 
 }  /* extern "C" */

@@ -464,3 +464,45 @@ def test_cpp_coder_round_trip_like_test_cpp(built, tmp_path):
         assert fields["ErrNum"] == "0" and float(fields["ThroughPut"]) > 0 and "sd" in fields and "Time" in fields
         assert any(l.startswith(mode + ":") for l in out.stdout.split())
     assert subprocess.run([mytest, "1"], capture_output=True).returncode == 2
+
+
+def test_device_channel_is_the_host_generator_bit_for_bit(built, tmp_path):
+    """ldpc_awgn_device (Coder::test on the GPU, counter-based noise) against the same header
+    evaluated on the host: every float identical, with and without code bits, for N % 4 != 0, for a
+    frame range that starts in the middle, and split ranges concatenate to the whole."""
+    import ctypes
+    import torch
+    from util import host_channel_lib
+    lib = host_channel_lib(tmp_path)
+    rng = np.random.default_rng(5)
+    for N, frames, first, sd in ((648, 70, 0, 0.8), (67, 33, 1000, 0.5), (64800, 3, (1 << 33) + 5, 0.95), (2304, 9, 7, 0.0)):
+        bits = rng.integers(0, 2, (frames, N)).astype(np.uint8)
+        for b in (None, bits):
+            want = np.empty((frames, N), np.float32)
+            lib.awgn(want.ctypes.data_as(ctypes.c_void_p), frames, N,
+                     None if b is None else b.ctypes.data_as(ctypes.c_void_p), sd, 99, first)
+            got = channel.awgn_device(N, first, frames, sd, seed=99,
+                                      codewords=None if b is None else torch.from_numpy(b).cuda())
+            assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), (N, frames, b is None)
+        whole = channel.awgn_device(N, first, frames, sd, seed=99)
+        k = frames // 3
+        parts = torch.cat([channel.awgn_device(N, first, k, sd, seed=99), channel.awgn_device(N, first + k, frames - k, sd, seed=99)])
+        assert torch.equal(whole, parts)
+    z = (channel.awgn_device(64800, 0, 64, 1.0, seed=1) - 1.0).double()
+    assert abs(z.mean().item()) < 4 / np.sqrt(z.numel()) and abs(z.var().item() - 1) < 0.005
+
+
+def test_device_error_count(built):
+    import torch
+    rng = np.random.default_rng(8)
+    frames, per = 37, 405
+    a = rng.integers(0, 256, (frames, per)).astype(np.uint8)
+    b = a.copy()
+    hit = rng.choice(frames * per, 300, replace=False)
+    b.reshape(-1)[hit] ^= rng.integers(1, 256, 300).astype(np.uint8)
+    b[5] = a[5]
+    x = a ^ b
+    want = (int(np.unpackbits(x).sum()), int((x != 0).sum()), int((x != 0).any(axis=1).sum()))
+    assert channel.count_errors_device(torch.from_numpy(b).cuda(), torch.from_numpy(a).cuda(), frames) == want
+    assert channel.count_errors_device(torch.from_numpy(x).cuda(), None, frames) == want
+    assert channel.count_errors_device(torch.zeros(frames * per, dtype=torch.uint8, device="cuda"), None, frames) == (0, 0, 0)

@@ -154,6 +154,34 @@ def test_shared_expf_matches_libm_on_a_sample(tmp_path):
     assert np.array_equal(y[idx].view(np.uint32), want.view(np.uint32))
 
 
+def test_counter_based_channel_generator(tmp_path):
+    """csrc/ldpc_channel.h on the host: Philox4x32-10 against the Random123 known-answer vectors,
+    and the normals it feeds (own log / sqrt / sin / cos in IEEE double) against N(0, 1)."""
+    from scipy import stats
+    from util import host_channel_lib
+    lib = host_channel_lib(tmp_path)
+    for ctr, key, want in (((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+                           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+                           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+                            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))):
+        c = (ctypes.c_uint32 * 4)(*ctr)
+        lib.philox(c, ctypes.c_uint32(key[0]), ctypes.c_uint32(key[1]))
+        assert tuple(c) == want
+    n = 1 << 19
+    z = np.empty(4 * n)
+    lib.normals(20260101, 3, n, z.ctypes.data_as(ctypes.c_void_p))
+    assert abs(z.mean()) < 4 / np.sqrt(z.size) and abs(z.var() - 1) < 6 * np.sqrt(2 / z.size)
+    assert abs(stats.skew(z)) < 0.01 and abs(stats.kurtosis(z)) < 0.02
+    assert stats.kstest(z[:300000], "norm").pvalue > 1e-3
+    assert abs((np.abs(z) > 3).mean() / (2 * stats.norm.sf(3)) - 1) < 0.1
+    assert abs(np.corrcoef(z[0::4], z[1::4])[0, 1]) < 0.01 and abs(np.corrcoef(z[:-1], z[1:])[0, 1]) < 0.01
+    # frames are independent streams, reproducible from (seed, frame) alone
+    a, b = np.empty(64), np.empty(64)
+    lib.normals(20260101, 3, 16, a.ctypes.data_as(ctypes.c_void_p))
+    lib.normals(20260101, 4, 16, b.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(a, z[:64]) and not np.array_equal(a, b)
+
+
 # ------------------------------------------------------------- oracle vs reference
 
 @pytest.mark.skipif(not os.path.exists("/root/reference/decodeCL.c"),
