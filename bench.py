@@ -35,6 +35,7 @@ N_CODE, K_CODE = 64800, 32400
 BATCH_PER_GPU = 4096
 ITERS = 50
 SIGMA = 0.95
+SEED = 20260101
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 # Extra measurement points (BASELINE.json configs[3], configs[4]); NOT the headline line.
@@ -71,9 +72,8 @@ def run_extra(name, args):
     g = L.Graph(rows, cols, M, N)
     dec = L.Decoder(g, K, max_batch=B, algo=c["algo"], max_iter=c["iters"], early_term=c["early"],
                     layer_rows=layer, msg_dtype=c["msg"], poll_interval=c["poll"], frames_per_lane=args.fpl)
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(20260101)
-    y = 1.0 + c["sigma"] * torch.randn(B, N, device="cuda", dtype=torch.float32, generator=gen)
+    from myldpccppapi_amd import channel
+    y = channel.awgn_device(N, 0, B, c["sigma"], seed=SEED)
     out = torch.empty(L.out_bytes(K, B), dtype=torch.uint8, device="cuda")
     it = torch.empty(B, dtype=torch.int32, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
@@ -123,7 +123,7 @@ def run_extra(name, args):
     dec.close()
 
 
-def cpu_baseline(rows, cols, seconds_budget=20.0):
+def cpu_baseline(rows, cols, seconds_budget=20.0, gpu_graph=None, gpu_y=None):
     """Reference CPU decode (min-sum, MyLdpc.cpp:684-784) via the oracle port, all host
     cores (frames split over threads; the C call releases the GIL) and one core."""
     from concurrent.futures import ThreadPoolExecutor
@@ -135,26 +135,44 @@ def cpu_baseline(rows, cols, seconds_budget=20.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    try:        # a container's CPU share (cgroup v2 quota) can be smaller than its affinity mask
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
     cores = max(1, min(cores, 64))
     # one frame first: calibrates the sample size (~0.3 s per frame-50-iterations per core)
-    y1 = channel.awgn_frames(N_CODE, 0, 1, SIGMA, seed=1234)
+    y1 = oracle.awgn(N_CODE, 0, 1, SIGMA, seed=SEED)
     t0 = time.perf_counter()
     oracle.decode(g, y1, "ms", max_iter=ITERS)
     t_one = time.perf_counter() - t0
     per_thread = max(1, min(8, int(seconds_budget / max(t_one, 1e-3) / cores)))
     frames = per_thread * cores
-    y = channel.awgn_frames(N_CODE, 1, frames, SIGMA, seed=1234)
+    y = oracle.awgn(N_CODE, 0, frames, SIGMA, seed=SEED)      # = the first frames of the GPU's batch
     chunks = [y[i * per_thread:(i + 1) * per_thread] for i in range(cores)]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(lambda c: oracle.decode(g, c, "ms", max_iter=ITERS), chunks))
+        outs = list(ex.map(lambda c: oracle.decode(g, c, "ms", max_iter=ITERS), chunks))
     dt = time.perf_counter() - t0
+    # the same frames, the same algorithm on the GPU: bytes and iteration counts must be identical
+    same = None
+    if gpu_graph is not None:
+        import myldpccppapi_amd as L
+        dec = L.Decoder(gpu_graph, K_CODE, max_batch=frames, algo="ms", max_iter=ITERS)
+        got, git = dec.decode(gpu_y[:frames].cpu().numpy())
+        same = bool(np.array_equal(got, np.concatenate([o["out"] for o in outs])) and
+                    np.array_equal(git, np.concatenate([o["iters"] for o in outs])) and
+                    np.array_equal(gpu_y[:frames].cpu().numpy().view(np.uint32), y.view(np.uint32)))
+        dec.close()
     return {
         "value": round(frames * K_CODE / dt / 1e6, 4), "unit": "Mbit/s", "cores": cores, "kind": "port",
         "one_core_mbit_s": round(K_CODE / t_one / 1e6, 4),
+        "same_frames_on_gpu_identical": same,
         "sample": "%d frames of the same code and noise (sigma=%.2f), %d iterations of the reference's CPU "
-                  "min-sum decoder (oracle port of MyLdpc.cpp:684-784), %d threads x %d frames, %.1f s wall"
-                  % (frames, SIGMA, ITERS, cores, per_thread, dt),
+                  "min-sum decoder (oracle port of MyLdpc.cpp:684-784), %d threads x %d frames, %.1f s wall; "
+                  "they are the first frames of the GPU's batch (same floats), and the GPU's min-sum decode of "
+                  "them is compared byte for byte" % (frames, SIGMA, ITERS, cores, per_thread, dt),
     }
 
 
@@ -206,9 +224,9 @@ def main():
                     early_term=True, device=local_rank)
     # synthetic channel: all-zero codeword + AWGN, generated in HBM, distinct per rank
     lo, hi = sharding.shard_range(B * world, rank, world)
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(20260101 + rank)
-    y = 1.0 + SIGMA * torch.randn(B, N_CODE, device="cuda", dtype=torch.float32, generator=gen)
+    # (counter-based noise, csrc/ldpc_channel.h: frame lo + i of the seed's stream, whatever the world size)
+    from myldpccppapi_amd import channel
+    y = channel.awgn_device(N_CODE, lo, B, SIGMA, seed=SEED, device=local_rank)
     out = torch.empty(L.out_bytes(K_CODE, B), dtype=torch.uint8, device="cuda")
     gathered = torch.empty(world * out.numel(), dtype=torch.uint8, device="cuda") if world > 1 else None
 
@@ -296,7 +314,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(rows, cols)
+            res["cpu_baseline"] = cpu_baseline(rows, cols, gpu_graph=g, gpu_y=y)
         print(json.dumps(res), flush=True)
     dec.close()
     if world > 1:

@@ -167,3 +167,15 @@ def test_channel(prior_bytes, sd, seed):
     post = np.empty(prior.size * 8, np.float32)
     lib().oracle_test_channel(_p(prior, _u8p), _p(post, _f32p), prior.size, ctypes.c_float(sd))
     return post
+
+
+def awgn(N, first_frame, frames, sd, seed=20260101, codewords=None):
+    """float32 [frames, N]: the counter-based channel of csrc/ldpc_channel.h evaluated on the host
+    (what ldpc_awgn_device produces on the GPU, float for float)."""
+    out = np.empty((frames, N), np.float32)
+    bits = None if codewords is None else np.ascontiguousarray(codewords, np.uint8)
+    f = lib().oracle_awgn
+    f.restype = None
+    f.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int32, _u8p, ctypes.c_float, ctypes.c_uint64, ctypes.c_int64]
+    f(_p(out, _f32p), frames, N, None if bits is None else _p(bits, _u8p), ctypes.c_float(sd), seed, first_frame)
+    return out

@@ -497,3 +497,21 @@ void oracle_test_channel(const uint8_t *prior, float *post, int64_t prior_len, f
             post[c * 8 + b] = (prior[c] & (1u << b)) ? -1.0f : 1.0f;
     for (int64_t i = 0; i < prior_len * 8; ++i) post[i] += box_muller(0, sd);
 }
+
+/* The benchmark's synthetic channel on the host: the counter-based generator the device uses
+ * (csrc/ldpc_channel.h, this project's own definition -- not reference behaviour), so that the CPU
+ * baseline decodes exactly the frames the GPU decodes ("seeded counter-based
+ * generator so host and device produce identical floats"). */
+#include "../myldpccppapi_amd/csrc/ldpc_channel.h"
+void oracle_awgn(float *llr, int64_t frames, int32_t N, const uint8_t *bits, float sd, uint64_t seed,
+                 int64_t first_frame)
+{
+    for (int64_t f = 0; f < frames; ++f)
+        for (int32_t g = 0; g < (N + 3) / 4; ++g) {
+            double z[4];
+            ldpc_ch_normal4(seed, (uint64_t)(first_frame + f), (uint32_t)g, z);
+            for (int i = 0; i < 4 && g * 4 + i < N; ++i)
+                llr[f * (int64_t)N + g * 4 + i] =
+                    ldpc_ch_sample(bits ? bits[f * (int64_t)N + g * 4 + i] & 1 : 0, sd, z[i]);
+        }
+}
