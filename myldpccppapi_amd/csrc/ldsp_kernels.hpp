@@ -55,7 +55,7 @@ struct LdspArgs {
     uint32_t *__restrict__ zf;            /* [grid][layers*z] "message is a zero" bits of irregular records */
     const int32_t *__restrict__ hdr;      /* [layers][4]: LDS entries, has external column, its first index, its shift */
     const int32_t *__restrict__ pack;     /* [layers][2][24]: byte offset of the entry's LDS column (slot*z*4), then
-                                             its shift: ready-made operands, no scalar arithmetic per edge */
+                                             4 * its shift: ready-made operands, no scalar arithmetic per edge */
     const int32_t *__restrict__ col_slot; /* [N/z]: LDS slot of the block column, -1 = travels with a record */
     const int32_t *__restrict__ layer_e0; /* [layers]: edge id of the layer's first edge */
     int64_t frames, out_bytes;
@@ -89,9 +89,13 @@ __device__ __forceinline__ int ldsp_wrap(int r, int shift, int z)   /* (r + shif
     return (int)(t < tw ? t : tw);
 }
 
-__device__ __forceinline__ float *ldsp_at(float *P, int column_bytes, int t)
+/* address of P[column][(r + shift) mod z] from ready-made byte quantities: r4 = 4r, shift4 = 4*shift,
+ * z4 = 4z, column_bytes = 4*slot*z -- add, subtract, unsigned minimum, add */
+__device__ __forceinline__ float *ldsp_at(float *P, int column_bytes, int shift4, int r4, int z4)
 {
-    return reinterpret_cast<float *>(reinterpret_cast<char *>(P) + column_bytes + t * 4);
+    const uint32_t t = (uint32_t)r4 + (uint32_t)shift4;
+    const uint32_t tw = t - (uint32_t)z4;                           /* wraps to a huge value when t < z4 */
+    return reinterpret_cast<float *>(reinterpret_cast<char *>(P) + ((t < tw ? t : tw) + (uint32_t)column_bytes));
 }
 
 /* Message k of a d-entry record: cl_sign(q) is +-1 for a regular q, so R = +-sel; it is +-0 for
@@ -116,7 +120,7 @@ __device__ __forceinline__ uint4 ldsp_row_any(float *P, ldpc_const_i32 pk, int d
         const float rold = __uint_as_float(ldsp_old_message(old, ozf, k, d));
         float q;
         if (k < dl) {
-            float *p = ldsp_at(P, pk[k], ldsp_wrap(r, pk[kLdspMaxDeg + k], z));
+            float *p = ldsp_at(P, pk[k], pk[kLdspMaxDeg + k], r * 4, z * 4);
             q = *p - rold;
             *p = q;
         } else {
@@ -136,7 +140,7 @@ __device__ __forceinline__ uint4 ldsp_row_any(float *P, ldpc_const_i32 pk, int d
         float *p = P;
         float q = qext;
         if (k < dl) {
-            p = ldsp_at(P, pk[k], ldsp_wrap(r, pk[kLdspMaxDeg + k], z));
+            p = ldsp_at(P, pk[k], pk[kLdspMaxDeg + k], r * 4, z * 4);
             q = *p;
         }
         const float rn = cl_sign(q) * ((k == bind) ? ac : ab);
@@ -168,7 +172,7 @@ __device__ __forceinline__ bool ldsp_row(float *P, ldpc_const_i32 pk, int z, int
     float q[D];
     float *at[DLA];
 #pragma unroll
-    for (int k = 0; k < DL; ++k) at[k] = ldsp_at(P, pk[k], ldsp_wrap(r, pk[kLdspMaxDeg + k], z));
+    for (int k = 0; k < DL; ++k) at[k] = ldsp_at(P, pk[k], pk[kLdspMaxDeg + k], r * 4, z * 4);
     const int obind = (int)((old.z >> 24) & 31u);
 #pragma unroll
     for (int k = 0; k < D; ++k) {
@@ -214,7 +218,7 @@ __device__ __forceinline__ uint64_t ldsp_row_parity(const float *P, ldpc_const_i
     constexpr int DLA = DL > 0 ? DL : 1;
     float v[DLA];
 #pragma unroll
-    for (int k = 0; k < DL; ++k) v[k] = *ldsp_at(const_cast<float *>(P), pk[k], ldsp_wrap(r, pk[kLdspMaxDeg + k], z));
+    for (int k = 0; k < DL; ++k) v[k] = *ldsp_at(const_cast<float *>(P), pk[k], pk[kLdspMaxDeg + k], r * 4, z * 4);
     uint64_t par = 0;
 #pragma unroll
     for (int k = 0; k < DL; ++k) par ^= __ballot(v[k] < 0.0f);
@@ -449,7 +453,7 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
         hdr[l * 4 + 3] = ext ? sh[last] : 0;
         for (int k = 0; k < d - ext; ++k) {
             pack[(size_t)l * 2 * kLdspMaxDeg + k] = slot[bc[lp[l] + k]] * z * 4;
-            pack[(size_t)l * 2 * kLdspMaxDeg + kLdspMaxDeg + k] = sh[lp[l] + k];
+            pack[(size_t)l * 2 * kLdspMaxDeg + kLdspMaxDeg + k] = sh[lp[l] + k] * 4;
         }
     }
     int mw = (z + 63) / 64;
@@ -469,7 +473,9 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
     if ((e = up(&pl->hdr, hdr)) || (e = up(&pl->pack, pack)) || (e = up(&pl->col_slot, slot)) || (e = up(&pl->layer_e0, e0)))
         return e;
     LdspKernel k = ldsp_kernel_for(pl->maxw);
-    if ((e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes))) return e;
+    /* the attribute belongs to the function, not to this plan: always the maximum, so that decoders
+     * of different codes can coexist */
+    if ((e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdspMaxLds))) return e;
     int per_cu = 0, cus = 0;
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, pl->block, lds_bytes))) return e;
     if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device))) return e;

@@ -160,6 +160,24 @@ def test_layered_bg1_profile_z384(built, monkeypatch):
     out2, it2 = dec.decode(y0)
     assert np.array_equal(out2, out0) and np.array_equal(it2, it0)
     dec.close()
+    # all 68 block columns in LDS (104 KB of dynamic LDS, one workgroup per CU), alive together with a
+    # decoder of a small code that uses the same kernel with 10 KB
+    monkeypatch.delenv("LDPC_TUNE_LDSP_GRID")
+    monkeypatch.setenv("LDPC_TUNE_LDSP_EXT", "0")
+    big = L.Decoder(g, Kb, max_batch=B, algo="layered", max_iter=20, layer_rows=Z)
+    monkeypatch.delenv("LDPC_TUNE_LDSP_EXT")
+    zs = 96
+    rs, cs = codes.qc_edges(codes.nr_bg1_profile_base(Z=zs), zs)
+    gs = L.Graph(rs, cs, 46 * zs, 68 * zs)
+    small = L.Decoder(gs, 22 * zs, max_batch=9, algo="layered", max_iter=20, layer_rows=zs)
+    ys = channel.awgn_frames(68 * zs, 0, 9, 0.8, seed=62)
+    outs, its = small.decode(ys)
+    out3, it3 = big.decode(y0)
+    assert np.array_equal(out3, out0) and np.array_equal(it3, it0)
+    os_ = oracle.decode(oracle.Graph(rs, cs, 46 * zs, 68 * zs, 22 * zs), ys, "layered", max_iter=20, layer_rows=zs)
+    assert np.array_equal(outs, os_["out"]) and np.array_equal(its, os_["iters"])
+    big.close()
+    small.close()
 
 
 def test_full_batch_4096_frames_indexing(built, code):
