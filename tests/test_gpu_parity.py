@@ -506,3 +506,4 @@ def test_device_error_count(built):
     assert channel.count_errors_device(torch.from_numpy(b).cuda(), torch.from_numpy(a).cuda(), frames) == want
     assert channel.count_errors_device(torch.from_numpy(x).cuda(), None, frames) == want
     assert channel.count_errors_device(torch.zeros(frames * per, dtype=torch.uint8, device="cuda"), None, frames) == (0, 0, 0)
+
