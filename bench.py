@@ -248,7 +248,9 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    dec.set_timing(True)            # per-launch HIP events on the launch stream, accumulated over the steps
+    # per-launch HIP events on the launch stream, inside the timed region: on two of the K steps (the
+    # events cost 2 % of a step, tools/gpu_timing_overhead.py), i.e. >= 100 launches of every kernel
+    dec.set_timing(max(1, args.steps // 2))
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -143,8 +143,10 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
 int64_t ldpc_out_bytes(int32_t K, int64_t frames, int32_t pack_mode);
 
 /* Per-kernel HIP-event timing of subsequent decode calls (two event records per
- * launch on the decode stream; off by default).  Enabling (again) clears what was
- * gathered; times then accumulate over all following calls.
+ * launch on the decode stream; off by default).  enable = 1: every call; enable = k > 1:
+ * every k-th ldpc_decode_device call, starting with the next one (the events cost about 2 %
+ * of a 4096-frame step, so a benchmark times a sample of its steps).  Enabling (again)
+ * clears what was gathered; times then accumulate over all following timed calls.
  * ldpc_decoder_stats: stats of the last call (ms_check/ms_var/ms_other: everything
  * gathered since timing was enabled); blocks until that call has finished. */
 int ldpc_decoder_set_timing(ldpc_decoder *d, int enable);

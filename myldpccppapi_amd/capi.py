@@ -103,6 +103,7 @@ class Decoder:
                                                   iters_ptr, stream))
 
     def set_timing(self, enable=True):
+        """True / 1: time every launch of every call; k > 1: of every k-th decode_device call; False: off."""
         _lib.check(_lib.load().ldpc_decoder_set_timing(self._h, int(enable)))
 
     def stats(self):

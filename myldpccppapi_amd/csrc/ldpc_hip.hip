@@ -224,7 +224,9 @@ struct ldpc_decoder {
     bool suppress_poll = false;
     int32_t *h_active = nullptr;        /* pinned */
 
-    bool timing = false;
+    bool timing = false;                /* the call being enqueued is timed */
+    int timing_every = 0;               /* 0 off, k: every k-th device call is timed */
+    int64_t timing_calls = 0;
     std::vector<TimedSpan> spans;
     size_t spans_used = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -789,6 +791,7 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
         return fail(LDPC_ERR_ARG, "out_bytes=%lld < %lld", (long long)out_bytes, (long long)need);
     HIP_TRY(hipSetDevice(d->cfg.device));
     hipStream_t s = (hipStream_t)stream;
+    d->timing = d->timing_every > 0 && (d->timing_calls++ % d->timing_every) == 0;
     d->last_stream = s;
     d->last_frames = frames;
     HIP_TRY(hipEventRecord(d->ev_begin, s));
@@ -935,7 +938,9 @@ int ldpc_decoder_set_timing(ldpc_decoder *d, int enable)
         HIP_TRY(hipSetDevice(d->cfg.device));
         HIP_TRY(hipEventSynchronize(d->ev_end));
     }
-    d->timing = enable != 0;
+    d->timing_every = enable > 0 ? enable : 0;
+    d->timing_calls = 0;
+    d->timing = false;
     d->spans_used = 0;
     return LDPC_OK;
 }

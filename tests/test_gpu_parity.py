@@ -507,3 +507,39 @@ def test_device_error_count(built):
     assert channel.count_errors_device(torch.from_numpy(x).cuda(), None, frames) == want
     assert channel.count_errors_device(torch.zeros(frames * per, dtype=torch.uint8, device="cuda"), None, frames) == (0, 0, 0)
 
+
+
+def test_per_launch_timing_hooks(built):
+    """set_timing: HIP events around every launch of the timed calls; 1 = every call, k = every k-th
+    call (what bench.py uses inside its timed region), 0 = off.  Results do not depend on it."""
+    g, og, K, M, z = _graph(codes.RATE_1_2, 2304)
+    y = channel.awgn_frames(2304, 0, 130, 0.95, seed=31)
+    want = oracle.decode(og, y, "sp", max_iter=12)
+    dec = L.Decoder(g, K, max_batch=130, algo="sp", max_iter=12, early_term=False)
+    out, iters = dec.decode(y)
+    assert np.array_equal(out, want["out"])
+    assert dec.kernel_times() == []
+    dec.set_timing(True)
+    for _ in range(2):
+        out, iters = dec.decode(y)
+    assert np.array_equal(out, want["out"]) and np.array_equal(iters, want["iters"])
+    kt = dec.kernel_times()
+    checks = [k for k in kt if k["phase"] == 0]
+    varn = [k for k in kt if k["phase"] == 1]
+    assert checks and varn and all(k["launches"] == 2 * 12 for k in checks + varn)
+    assert all(k["ms_total"] > 0 and k["bytes_total"] > 0 and "kernel<sp," in k["name"] for k in checks + varn)
+    # algorithmic bytes of the message kernels: 16 E + 4 N per frame-iteration (the last round's
+    # variable phase writes no Q: a little less)
+    total = sum(k["bytes_total"] for k in checks + varn)
+    full = 2 * 130 * (16 * g.E + 4 * 2304) * 12
+    assert 0.95 * full < total <= full
+    st = dec.stats()
+    assert st["ms_check"] > 0 and st["ms_var"] > 0 and st["launches_check"] == sum(k["launches"] for k in checks)
+    dec.set_timing(2)                      # calls 1 and 3 of the next four are timed
+    for _ in range(4):
+        dec.decode(y)
+    assert all(k["launches"] == 2 * 12 for k in dec.kernel_times() if k["phase"] in (0, 1))
+    dec.set_timing(False)
+    dec.decode(y)
+    assert dec.kernel_times() == []
+    dec.close()
