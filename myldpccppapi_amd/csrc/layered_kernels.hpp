@@ -375,8 +375,7 @@ inline hipError_t layered_run_v(LayeredPlan *pl, const LayeredRun &r, hipStream_
     PackArgs pa{r.hard, r.out_dev, r.iters, r.iters_dev, r.frames, r.out_bytes, pl->N, r.K, r.pack_mode};
     if (r.out_dev) {
         if (r.pack_mode == 0) {
-            dim3 grid((unsigned)r.frames, (r.K / 8 + kBlock - 1) / kBlock);
-            pack_kernel<V><<<grid, kBlock, 0, s>>>(pa);
+            pack_kernel<V><<<pack_grid<V>(r.K, tiles), kBlock, 0, s>>>(pa);
         } else {
             const int64_t n = r.out_bytes > r.frames ? r.out_bytes : r.frames;
             pack_kernel<V><<<(unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, s>>>(pa);

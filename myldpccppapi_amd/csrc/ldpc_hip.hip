@@ -417,9 +417,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
         PackArgs pa{d->hard.p, out_dev, d->iters.p, iters_dev, frames, out_bytes, d->N, d->cfg.K,
                     d->cfg.pack_mode};
         if (d->cfg.pack_mode == LDPC_PACK_BYTES) {
-            const int kb = d->cfg.K / 8;
-            dim3 grid((unsigned)frames, (kb + kBlock - 1) / kBlock);
-            if (out_dev && frames) pack_kernel<V><<<grid, kBlock, 0, s>>>(pa);
+            if (out_dev && frames) pack_kernel<V><<<pack_grid<V>(d->cfg.K, tiles), kBlock, 0, s>>>(pa);
         } else {
             const int64_t n = std::max<int64_t>(out_bytes, frames);
             dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
