@@ -543,3 +543,50 @@ def test_per_launch_timing_hooks(built):
     dec.decode(y)
     assert dec.kernel_times() == []
     dec.close()
+
+
+def test_layered_on_random_quasi_cyclic_codes(built, monkeypatch):
+    """Random QC structures (circulant sizes that are / are not multiples of 64, single-layer
+    columns in every position, rows of weight 1 to 24, one layer only, information parts that end
+    inside a block column): the three layered implementations -- LDS-resident, LDS posterior +
+    cached check records, one launch per layer -- against the oracle, bytes and iteration counts."""
+    rng = np.random.default_rng(20261004)
+    cases = []
+    for z, mb, nb, dmax in ((5, 3, 9, 5), (17, 6, 14, 6), (64, 4, 12, 8), (65, 5, 30, 24), (100, 1, 10, 10),
+                            (40, 8, 12, 3), (96, 12, 36, 7), (130, 3, 26, 24), (24, 10, 16, 2), (33, 7, 40, 20)):
+        base = -np.ones((mb, nb), np.int64)
+        for i in range(mb):
+            d = int(rng.integers(1, min(dmax, nb) + 1))
+            base[i, rng.choice(nb, d, replace=False)] = rng.integers(0, z, d)
+        for j in range(nb):                       # every column is checked at least once
+            if (base[:, j] < 0).all():
+                i = int(rng.integers(0, mb))
+                if (base[i] >= 0).sum() < 24:
+                    base[i, j] = rng.integers(0, z)
+        keep = [j for j in range(nb) if (base[:, j] >= 0).any()]
+        base = base[:, keep]
+        nb = len(keep)
+        K = max(8, ((nb - min(mb, nb - 1)) * z - int(rng.integers(0, z))) // 8 * 8)
+        cases.append((z, base, min(K, nb * z // 8 * 8)))
+    for z, base, K in cases:
+        mb, nb = base.shape
+        rows, cols = codes.qc_edges(base, z)
+        M, N = mb * z, nb * z
+        g = L.Graph(rows, cols, M, N)
+        og = oracle.Graph(rows, cols, M, N, K)
+        B = 11
+        sigma = 0.9 if M * 2 > N else 0.6
+        y = channel.awgn_frames(N, 0, B, sigma, seed=z)
+        y[3, ::3] = 0.0                           # zeros: rows that take the slow path of the record kernel
+        want = oracle.decode(og, y, "layered", layer_rows=z, max_iter=9)
+        ok = want["undefined"] == 0 if "undefined" in want else np.ones(B, bool)
+        kb = K // 8
+        for mode in ("fused", "ldsp", "stream"):
+            monkeypatch.setenv("LDPC_TUNE_FUSED", "0" if mode == "stream" else "1")
+            monkeypatch.setenv("LDPC_TUNE_LDSP", "1" if mode == "ldsp" else "0")
+            monkeypatch.setenv("LDPC_TUNE_LDSP_GRID", "3")
+            dec = L.Decoder(g, K, max_batch=B, algo="layered", layer_rows=z, max_iter=9)
+            out, iters = dec.decode(y)
+            assert np.array_equal(out.reshape(B, kb)[ok], want["out"].reshape(B, kb)[ok]), (z, base.shape, K, mode)
+            assert np.array_equal(iters[ok], want["iters"][ok]), (z, base.shape, K, mode)
+            dec.close()
