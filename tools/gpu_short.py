@@ -15,8 +15,9 @@ torch.manual_seed(1)
 y = 1.0 + sigma * torch.randn(B, N, device="cuda")
 out = torch.empty(L.out_bytes(K, B), dtype=torch.uint8, device="cuda")
 it = torch.empty(B, dtype=torch.int32, device="cuda")
-for fused in ("1", "0"):
-    os.environ["LDPC_TUNE_FUSED"] = fused
+for fused in ("1", "ldsp", "0") if algo == "layered" else ("1", "0"):
+    os.environ["LDPC_TUNE_FUSED"] = "1" if fused == "ldsp" else fused
+    os.environ["LDPC_TUNE_LDSP"] = "1" if fused == "ldsp" else "0"
     dec = L.Decoder(g, K, max_batch=B, algo=algo, layer_rows=z, max_iter=40, poll_interval=0)
     for _ in range(2):
         dec.decode_device(y.data_ptr(), B, out.data_ptr(), out.numel(), it.data_ptr(), None)
