@@ -723,11 +723,11 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
             d->use_fused = d->fused.eligible;
             /* layered_ldsp_kernel (posterior in LDS, 16-byte check records in cache) is the default for
              * every QC code it fits: larger codes cannot use the fully LDS-resident kernel at all, and on
-             * short ones it is 1.2-2.6x faster (exact-width rows, bit-level sign algebra: 800 against 280 G
-             * edge updates/s) -- except for circulants of <= 32 rows, where the LDS-resident kernel packs
-             * several frames into one wave.  LDPC_TUNE_LDSP=1 / 0 forces / forbids it. */
+             * short ones it is 1.2-2.9x faster (exact-width rows, bit-level sign algebra: 800 against 280 G
+             * edge updates/s; circulants of <= 32 rows run several frames per wave in both).
+             * LDPC_TUNE_LDSP=0 forbids it (the LDS-resident kernel is then used where it applies). */
             const char *le = getenv("LDPC_TUNE_LDSP");
-            if (le ? atoi(le) != 0 : (!d->use_fused || cfg->layer_rows > 32)) {
+            if (le ? atoi(le) != 0 : true) {
                 HIP_TRY(ldpc::ldsp_plan_create(&d->ldsp, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows,
                                                cfg->K, cfg->max_batch, cfg->device));
                 if (d->ldsp.eligible) d->use_fused = d->use_ldsp = true;

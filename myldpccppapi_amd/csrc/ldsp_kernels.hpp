@@ -228,9 +228,10 @@ __device__ __forceinline__ uint64_t ldsp_row_parity(const float *P, ldpc_const_i
 #define LDPC_LDSP_WIDTHS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) \
     X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23)
 
-/* Register budget: at BG1 Z = 384 a workgroup is 6 waves and 40 KB of LDS; three workgroups per
- * CU (18 waves, 4.5 per SIMD) already keep the vector ALUs as busy as four do, and 96 VGPRs
- * hold the widest rows (19 + 1 entries) without spilling. */
+/* Register budget: at BG1 Z = 384 a workgroup is 6 waves and 40 KB of LDS.  The dispatcher places
+ * a workgroup's waves 2-2-1-1 on the four SIMDs, so three workgroups per CU need room for 6 waves
+ * on a SIMD, i.e. at most 80 VGPRs (measured: 96 VGPRs -> two workgroups per CU, 30 ms instead of
+ * 25 ms per batch; the widest rows, 19 + 1 entries, spill a few registers at 80). */
 #ifndef LDPC_LDSP_WAVES_PER_EU
 #define LDPC_LDSP_WAVES_PER_EU 6
 #endif
@@ -392,6 +393,159 @@ void layered_ldsp_kernel(const LdspArgs a)
     }
 }
 
+
+/* Circulants of <= 32 rows (the reference's own Test.cpp code: z = 24): G = 64 / z frames share one
+ * wave -- lanes [g z, (g + 1) z) are the rows of frame g -- each with its own posteriors in LDS and
+ * its own record ring.  One wave per workgroup, so "barriers" only order the wave's own LDS
+ * traffic; a frame whose syndrome is clean goes idle until the wave's last frame is done. */
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LDPC_LDSP_WAVES_PER_EU)))
+void layered_ldsp_packed_kernel(const LdspArgs a, const int G)
+{
+    extern __shared__ float lds[];
+    const int lane = (int)threadIdx.x;
+    const int z = a.z;
+    const int g = lane / z, r = lane - g * z;
+    const bool member = g < G;                                      /* lane belongs to a frame slot */
+    const size_t frame_floats = ((size_t)a.lds_cols * z + 1) & ~(size_t)1;
+    float *P = lds + (size_t)(member ? g : 0) * frame_floats;       /* [lds_cols][z] of my frame */
+    uint64_t *extneg = reinterpret_cast<uint64_t *>(lds + (size_t)G * frame_floats);   /* [layers] lane masks */
+    const size_t ring = ((size_t)blockIdx.x * G + (member ? g : 0)) * ((size_t)a.layers * z) + r;
+    uint4 *recs = a.recs + ring;
+    uint32_t *zfs = a.zf + ring;
+    const ldpc_const_i32 hdr = as_constant(a.hdr), pack = as_constant(a.pack), cslot = as_constant(a.col_slot);
+    const uint64_t gmask = (z >= 64 ? ~0ull : ((1ull << z) - 1ull)) << (member ? g * z : 0);
+    for (int64_t frame0 = (int64_t)blockIdx.x * G; frame0 < a.frames; frame0 += (int64_t)gridDim.x * G) {
+        const int64_t frame = frame0 + g;
+        const bool mine = member && frame < a.frames;
+        const float *y = a.llr + (size_t)(mine ? frame : 0) * a.N;
+        if (mine) {
+            for (int bc = 0; bc < a.nb; ++bc) {
+                const int slot = cslot[bc];
+                if (slot >= 0) P[slot * z + r] = y[bc * z + r];
+            }
+            for (int l = 0; l < a.layers; ++l) {
+                uint4 rec = uint4{0u, 0u, 0u, 0u};
+                if (hdr[l * 4 + 1]) rec.w = __float_as_uint(y[hdr[l * 4 + 2] + ldsp_wrap(r, hdr[l * 4 + 3], z)]);
+                recs[(size_t)l * z] = rec;
+            }
+        }
+        uint4 cur = uint4{0u, 0u, 0u, 0u};
+        if (mine) cur = recs[0];
+        lds_barrier();
+        int time = 0, my_iters = a.max_iter;
+        bool active = mine, clean = false;
+        while (__ballot(active) != 0ull) {
+            uint32_t last_bad = 0;
+            for (int l = 0; l < a.layers; ++l) {
+                const int ln = l + 1 < a.layers ? l + 1 : 0;
+                uint4 nxt = uint4{0u, 0u, 0u, 0u};
+                if (active && a.layers > 1) nxt = recs[(size_t)ln * z];
+                const int dl = hdr[l * 4], ext = hdr[l * 4 + 1];
+                const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
+                if (active) {
+                    uint4 rec;
+                    uint32_t par = 0;
+                    bool done = false;
+                    if (ext) {
+                        switch (dl) {
+#define LDPC_LDSP_CASE(D) case D: done = ldsp_row<D, 1>(P, pk, z, r, cur, &rec, &par); break;
+                            LDPC_LDSP_WIDTHS(LDPC_LDSP_CASE)
+#undef LDPC_LDSP_CASE
+                        default: break;
+                        }
+                    } else {
+                        switch (dl) {
+#define LDPC_LDSP_CASE(D) case D + 1: done = ldsp_row<D + 1, 0>(P, pk, z, r, cur, &rec, &par); break;
+                            LDPC_LDSP_WIDTHS(LDPC_LDSP_CASE)
+#undef LDPC_LDSP_CASE
+                        default: break;
+                        }
+                    }
+                    if (!done) rec = ldsp_row_any(P, pk, dl, ext, z, r, cur, zfs + (size_t)l * z, &par);
+                    last_bad = par;
+                    asm volatile("" : "+v"(nxt.x), "+v"(nxt.y), "+v"(nxt.z), "+v"(nxt.w) : : "memory");
+                    recs[(size_t)l * z] = rec;
+                    if (a.layers == 1) nxt = rec;
+                    if (ext) {
+                        const uint64_t neg = __ballot(__uint_as_float(rec.w) < 0.0f);
+                        const uint64_t act = __ballot(true);
+                        if (lane == (int)__builtin_ctzll(act)) extneg[l] = neg;
+                    }
+                }
+                lds_barrier();
+                cur = nxt;
+            }
+            ++time;
+            const bool check = a.early_term || time == a.rounds;
+            const uint64_t last_mask = __ballot(active && last_bad);
+            bool any_bad = true;
+            if (check && __ballot(active && (last_mask & gmask) == 0ull) != 0ull) {
+                /* some frame's last layer is all even: the full syndrome, for the frames that need it */
+                uint64_t bad = 0;
+                const bool need = active && (last_mask & gmask) == 0ull;
+                if (need) {
+                    for (int l = 0; l < a.layers; ++l) {
+                        const int dl = hdr[l * 4], ext = hdr[l * 4 + 1];
+                        const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
+                        uint64_t par = 0;
+                        switch (dl) {
+#define LDPC_LDSP_CASE(D) case D + 1: par = ldsp_row_parity<D + 1>(P, pk, z, r); break;
+                            LDPC_LDSP_WIDTHS(LDPC_LDSP_CASE)
+#undef LDPC_LDSP_CASE
+                        default: break;
+                        }
+                        if (ext) par ^= extneg[l];
+                        bad |= par;
+                    }
+                    any_bad = (bad & gmask) != 0ull;
+                }
+            }
+            if (active) {
+                clean = check && !any_bad;
+                if ((clean && a.early_term) || time == a.rounds) {
+                    active = false;
+                    my_iters = clean ? time : a.max_iter;
+                }
+            }
+            lds_barrier();
+        }
+        if (mine) {
+            const int64_t base = frame * (int64_t)a.K / 8;
+            for (int j = r; j < a.K / 8; j += z) {
+                unsigned byte = 0;
+#pragma unroll
+                for (int bit = 0; bit < 8; ++bit) byte |= (P[j * 8 + bit] < 0.0f ? 1u : 0u) << bit;
+                if (base + j < a.out_bytes) a.out[base + j] = (uint8_t)byte;
+            }
+            if (a.dump_p) {
+                for (int bc = 0; bc < a.nb; ++bc) {
+                    const int slot = cslot[bc];
+                    if (slot >= 0) a.dump_p[(size_t)frame * a.N + bc * z + r] = P[slot * z + r];
+                }
+                for (int l = 0; l < a.layers; ++l)
+                    if (hdr[l * 4 + 1])
+                        a.dump_p[(size_t)frame * a.N + hdr[l * 4 + 2] + ldsp_wrap(r, hdr[l * 4 + 3], z)] =
+                            __uint_as_float(recs[(size_t)l * z].w);
+            }
+            if (a.dump_r) {
+                for (int l = 0; l < a.layers; ++l) {
+                    const int d = hdr[l * 4] + hdr[l * 4 + 1], e0 = a.layer_e0[l];
+                    const uint4 rec = recs[(size_t)l * z];
+                    const uint32_t zf = (rec.z & kLdspIrregular) ? zfs[(size_t)l * z] : 0u;
+                    for (int k = 0; k < d; ++k)
+                        a.dump_r[(size_t)frame * a.E + e0 + r * d + k] = __uint_as_float(ldsp_old_message(rec, zf, k, d));
+                }
+            }
+            if (r == 0) {
+                if (a.iters) a.iters[frame] = my_iters;
+                atomicMax(&a.summary[0], my_iters);
+                if (clean) atomicAdd(&a.summary[1], 1);
+            }
+        }
+        lds_barrier();                                             /* P is refilled for the next frames */
+    }
+}
+
 /* ---------------------------------------------------------------- host side */
 
 struct LdspPlan {
@@ -402,7 +556,7 @@ struct LdspPlan {
     uint32_t *zf = nullptr;
     float *dump_p = nullptr, *dump_r = nullptr;
     int64_t dump_frames = 0;
-    int32_t grid = 0, block = 0, maxw = 0, per_cu = 0;
+    int32_t grid = 0, block = 0, maxw = 0, per_cu = 0, wg_frames = 1;   /* wg_frames: frames per one-wave workgroup (z <= 32) */
     size_t lds_bytes = 0;
 };
 
@@ -458,8 +612,16 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
     }
     int mw = (z + 63) / 64;
     if (const char *t = getenv("LDPC_TUNE_LDSP_WAVES")) mw = std::min(16, std::max(mw, atoi(t)));   /* idle waves appended */
-    const size_t lds_bytes = ((((size_t)lds_cols * z + 1) & ~(size_t)1)) * sizeof(float) + (size_t)layers * mw * sizeof(uint64_t) + 8;
+    int frames_per_wg = 1;
+    {
+        const char *pe = getenv("LDPC_TUNE_LDSP_PACK");
+        if (mw == 1 && z <= 32 && !(pe && atoi(pe) == 0)) frames_per_wg = 64 / z;
+    }
+    const size_t frame_bytes = ((((size_t)lds_cols * z + 1) & ~(size_t)1)) * sizeof(float);
+    while (frames_per_wg > 1 && frames_per_wg * frame_bytes + (size_t)layers * sizeof(uint64_t) + 8 > 60 * 1024) --frames_per_wg;
+    const size_t lds_bytes = frames_per_wg * frame_bytes + (size_t)layers * mw * sizeof(uint64_t) + 8;
     if (lds_bytes > kLdspMaxLds || lds_cols >= 32768) return hipSuccess;
+    pl->wg_frames = frames_per_wg;
     pl->z = z; pl->layers = layers; pl->N = N; pl->E = (int32_t)E; pl->M = M; pl->nb = nb;
     pl->lds_cols = lds_cols; pl->ext_cols = ext_cols; pl->lds_bytes = lds_bytes;
     pl->maxw = mw <= 8 ? 8 : 16;
@@ -472,20 +634,20 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
     hipError_t e;
     if ((e = up(&pl->hdr, hdr)) || (e = up(&pl->pack, pack)) || (e = up(&pl->col_slot, slot)) || (e = up(&pl->layer_e0, e0)))
         return e;
-    LdspKernel k = ldsp_kernel_for(pl->maxw);
+    const void *k = pl->wg_frames > 1 ? (const void *)layered_ldsp_packed_kernel : (const void *)ldsp_kernel_for(pl->maxw);
     /* the attribute belongs to the function, not to this plan: always the maximum, so that decoders
      * of different codes can coexist */
-    if ((e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdspMaxLds))) return e;
+    if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdspMaxLds))) return e;
     int per_cu = 0, cus = 0;
-    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, pl->block, lds_bytes))) return e;
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, pl->block, lds_bytes))) return e;
     if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device))) return e;
     if (per_cu < 1 || cus < 1) return hipErrorInvalidValue;
     if (const char *t = getenv("LDPC_TUNE_LDSP_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(t)));
     pl->per_cu = per_cu;
-    pl->grid = (int32_t)std::min<int64_t>(std::max<int64_t>(max_batch, 1), (int64_t)per_cu * cus);
+    pl->grid = (int32_t)std::min<int64_t>((std::max<int64_t>(max_batch, 1) + pl->wg_frames - 1) / pl->wg_frames, (int64_t)per_cu * cus);
     if (const char *t = getenv("LDPC_TUNE_LDSP_GRID")) pl->grid = std::max(1, std::min(pl->grid, atoi(t)));
-    if ((e = hipMalloc((void **)&pl->recs, (size_t)pl->grid * M * sizeof(uint4)))) return e;
-    if ((e = hipMalloc((void **)&pl->zf, (size_t)pl->grid * M * sizeof(uint32_t)))) return e;
+    if ((e = hipMalloc((void **)&pl->recs, (size_t)pl->grid * pl->wg_frames * M * sizeof(uint4)))) return e;
+    if ((e = hipMalloc((void **)&pl->zf, (size_t)pl->grid * pl->wg_frames * M * sizeof(uint32_t)))) return e;
     pl->eligible = true;
     return hipSuccess;
 }
@@ -508,9 +670,10 @@ inline hipError_t ldsp_run(LdspPlan *pl, const FusedRun &r, hipStream_t s, int32
                r.tap_iter ? pl->dump_r : nullptr, pl->recs, pl->zf, pl->hdr, pl->pack, pl->col_slot, pl->layer_e0,
                r.frames, r.out_dev ? r.out_bytes : 0, pl->N, pl->E, r.K, pl->z, pl->layers, pl->nb, pl->lds_cols,
                r.max_iter, rounds, r.early_term};
-    const unsigned grid = (unsigned)std::min<int64_t>(r.frames, pl->grid);
+    const unsigned grid = (unsigned)std::min<int64_t>((r.frames + pl->wg_frames - 1) / pl->wg_frames, pl->grid);
     if (!pl->eligible || grid == 0) return hipErrorInvalidValue;
-    ldsp_kernel_for(pl->maxw)<<<grid, pl->block, pl->lds_bytes, s>>>(a);
+    if (pl->wg_frames > 1) layered_ldsp_packed_kernel<<<grid, 64, pl->lds_bytes, s>>>(a, pl->wg_frames);
+    else ldsp_kernel_for(pl->maxw)<<<grid, pl->block, pl->lds_bytes, s>>>(a);
     *launched = rounds;
     return hipGetLastError();
 }
