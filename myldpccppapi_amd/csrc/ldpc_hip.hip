@@ -751,10 +751,26 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
         if (cfg->msg_dtype == LDPC_MSG_F32 && cfg->layer_rows > 0 && cfg->frames_per_lane == 0 &&
             (cfg->pack_mode == LDPC_PACK_BYTES || cfg->K % 8 == 0)) {
             const char *fe = getenv("LDPC_TUNE_FUSED");
+            const char *le = getenv("LDPC_TUNE_LDSP");
+
             const bool small = (int64_t)cfg->max_batch * g->E <= (int64_t)1 << 23;
             if (fe ? atoi(fe) != 0 : small) {
                 HIP_TRY(ldpc::fused_plan_create(&d->fused, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows));
                 d->use_fused = d->fused.eligible && (cfg->algo == LDPC_ALGO_MS || d->fused.eligible_sp);
+            }
+            /* min-sum: posteriors in LDS, one 16-byte record per check row (flood_ldsp_kernel).  Default
+             * wherever its two posterior images leave room for >= 4 workgroups per CU (every 802.16e
+             * size): 2-2.9x the LDS-resident kernel and the streaming kernels at any batch size
+             * ((2304, 1152): 9.9 / 4.0 / 2.9 Gbit/s at 16 384 frames, 2.6 / 0.9 / 1.3 at full work); larger
+             * codes (BG1 Z >= 128: 2 workgroups per CU) only match the streaming kernels and keep them.
+             * LDPC_TUNE_LDSP=1 / 0 forces / forbids it. */
+            if (cfg->algo == LDPC_ALGO_MS && !(fe && atoi(fe) == 0) && !(le && atoi(le) == 0)) {
+                HIP_TRY(ldpc::ldsp_plan_create(&d->ldsp, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows,
+                                               cfg->K, cfg->max_batch, cfg->device, /*flood=*/true));
+                if (d->ldsp.eligible && ((le && atoi(le) != 0) || d->ldsp.lds_bytes <= 40 * 1024))
+                    d->use_fused = d->use_ldsp = true;
+                else
+                    ldpc::ldsp_plan_destroy(&d->ldsp);
             }
         }
         if (!d->use_fused) {
@@ -997,7 +1013,7 @@ int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t ca
             out[k].degree = sp.degree;
             if (sp.kind == 3) snprintf(out[k].name, sizeof out[k].name, "other");
             else if (d->use_fused)      /* whole decode in one launch; bytes = channel values in + packed bits out */
-                snprintf(out[k].name, sizeof out[k].name, "%s", d->use_ldsp ? "layered_ldsp_kernel"
+                snprintf(out[k].name, sizeof out[k].name, "%s", d->use_ldsp ? (d->cfg.algo == LDPC_ALGO_MS ? "flood_ldsp_kernel" : "layered_ldsp_kernel")
                          : d->cfg.algo == LDPC_ALGO_SP ? "fused_sp_kernel"
                          : d->cfg.algo == LDPC_ALGO_LAYERED ? "fused_layered_kernel" : "fused_flood_kernel");
             else snprintf(out[k].name, sizeof out[k].name, "%s<%s,%d,%d>", phase_name[sp.kind],

@@ -546,6 +546,184 @@ void layered_ldsp_packed_kernel(const LdspArgs a, const int G)
     }
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * Flooding min-sum (DecodeMS / DecodeCPU: the arithmetic of refreshRMS, refreshPostPMS,
+ * refreshQMS, decodeCL.c:113-186) with the same placement: posteriors in LDS, one 16-byte record
+ * per check row {min1, min2, signs | argmin}.  Every R_k = +-min is exactly (magnitude, sign bit),
+ * so there is no irregular case here.  Per iteration every row reads the OLD posteriors
+ * (q_k = P_old[col] - R_old,k is refreshQMS applied on the fly), and adds its new messages to the
+ * NEW posteriors, which start from the channel values: two LDS images, layers in ascending order
+ * with a barrier in between, so that every column receives y + R_1 + R_2 + ... in ascending row
+ * order as refreshPostPMS computes it.  Hard decision !(p > 0), syndrome, stop when clean. */
+template <int D>
+__device__ __forceinline__ void ldsp_flood_row(const float *Pold, float *Pnew, ldpc_const_i32 pk, int z, int r,
+                                               const uint4 old, uint4 *out, uint64_t *par_mask)
+{
+    float q[D];
+    uint32_t off[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const uint32_t t = (uint32_t)(r * 4) + (uint32_t)pk[kLdspMaxDeg + k];
+        const uint32_t tw = t - (uint32_t)(z * 4);
+        off[k] = (t < tw ? t : tw) + (uint32_t)pk[k];
+    }
+    const int oidx = (int)((old.z >> 24) & 31u);
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const uint32_t sel = (k == oidx) ? old.y : old.x;
+        const uint32_t rold = ((old.z << (31 - (D - 1 - k))) & 0x80000000u) | sel;
+        q[k] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(Pold) + off[k]) - __uint_as_float(rold);
+    }
+    float m1 = 1000.0f, m2 = 1000.0f;
+    int idx = 31;                                                   /* none */
+    uint32_t par = 0, neg[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const float mag = __builtin_fabsf(q[k]);
+        neg[k] = (q[k] < 0.0f) ? 0x80000000u : 0u;
+        par ^= neg[k];
+        const bool lt1 = mag < m1, lt2 = mag < m2;                  /* NaN: neither */
+        m2 = lt1 ? m1 : (lt2 ? mag : m2);
+        m1 = lt1 ? mag : m1;
+        idx = lt1 ? k : idx;
+    }
+    const uint32_t b1 = __float_as_uint(m1), b2 = __float_as_uint(m2);
+    uint32_t signs = 0;
+    uint64_t pm = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const uint32_t rn = ((k == idx) ? b2 : b1) ^ (par ^ neg[k]);    /* s ? -b : b, b >= 0 */
+        float *p = reinterpret_cast<float *>(reinterpret_cast<char *>(Pnew) + off[k]);
+        const float pn = *p + __uint_as_float(rn);
+        *p = pn;
+        signs = __builtin_amdgcn_alignbit(signs, rn, 31);
+        pm ^= __ballot(!(pn > 0.0f));
+    }
+    *out = uint4{b1, b2, signs | ((uint32_t)idx << 24), 0u};
+    *par_mask = pm;
+}
+
+template <int D>
+__device__ __forceinline__ uint64_t ldsp_flood_parity(const float *P, ldpc_const_i32 pk, int z, int r)
+{
+    float v[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) v[k] = *ldsp_at(const_cast<float *>(P), pk[k], pk[kLdspMaxDeg + k], r * 4, z * 4);
+    uint64_t par = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) par ^= __ballot(!(v[k] > 0.0f));
+    return par;
+}
+
+#define LDPC_LDSP_WIDTHS1(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) \
+    X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
+
+template <int MAXW>
+__global__ __launch_bounds__(64 * MAXW) __attribute__((amdgpu_waves_per_eu(LDPC_LDSP_WAVES_PER_EU)))
+void flood_ldsp_kernel(const LdspArgs a)
+{
+    extern __shared__ float lds[];
+    const int r = (int)threadIdx.x, LANES = (int)blockDim.x;
+    const int z = a.z;
+    const size_t image = ((size_t)a.N + 1) & ~(size_t)1;
+    float *Pa = lds, *Pb = lds + image;                             /* old / new posteriors, [N] each */
+    uint32_t *wg_flag = reinterpret_cast<uint32_t *>(lds + 2 * image);
+    const bool row = r < z;
+    uint4 *recs = a.recs + (size_t)blockIdx.x * ((size_t)a.layers * z) + r;
+    const ldpc_const_i32 hdr = as_constant(a.hdr), pack = as_constant(a.pack);
+    auto wg_any = [&](bool pred) {
+        if (r == 0) *wg_flag = 0u;
+        lds_barrier();
+        if (__ballot(pred) != 0ull && (r & 63) == 0) *wg_flag = 1u;
+        lds_barrier();
+        const uint32_t f = *wg_flag;
+        lds_barrier();
+        return f != 0u;
+    };
+    for (int64_t frame = blockIdx.x; frame < a.frames; frame += gridDim.x) {
+        const float *y = a.llr + (size_t)frame * a.N;
+        for (int n = r; n < a.N; n += LANES) Pa[n] = y[n];         /* Q_0 = y: P_0 = y, R_0 = 0 */
+        int time = 0;
+        bool clean = false;
+        uint4 cur = uint4{0u, 0u, 0u, 0u};
+        while (true) {
+            for (int n = r; n < a.N; n += LANES) Pb[n] = y[n];     /* refreshPostPMS starts from the channel value */
+            __syncthreads();
+            uint64_t last_bad = 0;
+            for (int l = 0; l < a.layers; ++l) {
+                const int ln = l + 1 < a.layers ? l + 1 : 0;
+                uint4 nxt = uint4{0u, 0u, 0u, 0u};
+                if (row && a.layers > 1 && (time > 0 || ln == 0)) nxt = recs[(size_t)ln * z];
+                const int d = hdr[l * 4];
+                const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
+                if (row) {
+                    uint4 rec = cur;
+                    uint64_t pm = 0;
+                    switch (d) {
+#define LDPC_LDSP_CASE(D) case D: ldsp_flood_row<D>(Pa, Pb, pk, z, r, cur, &rec, &pm); break;
+                        LDPC_LDSP_WIDTHS1(LDPC_LDSP_CASE)
+#undef LDPC_LDSP_CASE
+                    default: break;
+                    }
+                    last_bad = pm;
+                    asm volatile("" : "+v"(nxt.x), "+v"(nxt.y), "+v"(nxt.z), "+v"(nxt.w) : : "memory");
+                    recs[(size_t)l * z] = rec;
+                    if (a.layers == 1) nxt = rec;
+                }
+                lds_barrier();
+                cur = nxt;
+            }
+            ++time;
+            int any_bad = 1;
+            /* the last layer's rows have just written the final posteriors of their columns */
+            if ((a.early_term || time == a.rounds) && !wg_any(row && last_bad != 0ull)) {
+                uint64_t bad = 0;
+                if (row) {
+                    for (int l = 0; l < a.layers; ++l) {
+                        const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
+                        switch (hdr[l * 4]) {
+#define LDPC_LDSP_CASE(D) case D: bad |= ldsp_flood_parity<D>(Pb, pk, z, r); break;
+                            LDPC_LDSP_WIDTHS1(LDPC_LDSP_CASE)
+#undef LDPC_LDSP_CASE
+                        default: break;
+                        }
+                    }
+                }
+                any_bad = wg_any(bad != 0ull) ? 1 : 0;
+            }
+            clean = !any_bad;
+            float *t = Pa; Pa = Pb; Pb = t;                         /* the new posteriors are the next round's old ones */
+            if ((clean && a.early_term) || time == a.rounds) break;
+        }
+        /* Pa holds the final posteriors */
+        const int64_t base = frame * (int64_t)a.K / 8;
+        for (int j = r; j < a.K / 8; j += LANES) {
+            unsigned byte = 0;
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) byte |= (!(Pa[j * 8 + bit] > 0.0f) ? 1u : 0u) << bit;
+            if (base + j < a.out_bytes) a.out[base + j] = (uint8_t)byte;
+        }
+        if (a.dump_p)
+            for (int n = r; n < a.N; n += LANES) a.dump_p[(size_t)frame * a.N + n] = Pa[n];
+        if (a.dump_r && row) {
+            for (int l = 0; l < a.layers; ++l) {
+                const int d = hdr[l * 4], e0 = a.layer_e0[l];
+                const uint4 rec = recs[(size_t)l * z];
+                for (int k = 0; k < d; ++k)
+                    a.dump_r[(size_t)frame * a.E + e0 + r * d + k] = __uint_as_float(ldsp_old_message(rec, 0u, k, d));
+            }
+        }
+        if (r == 0) {
+            const int it = clean ? time : a.max_iter;
+            if (a.iters) a.iters[frame] = it;
+            atomicMax(&a.summary[0], it);
+            if (clean) atomicAdd(&a.summary[1], 1);
+        }
+        __syncthreads();
+    }
+}
+
 /* ---------------------------------------------------------------- host side */
 
 struct LdspPlan {
@@ -556,6 +734,7 @@ struct LdspPlan {
     uint32_t *zf = nullptr;
     float *dump_p = nullptr, *dump_r = nullptr;
     int64_t dump_frames = 0;
+    bool flood = false;                 /* flood_ldsp_kernel (flooding min-sum) instead of the layered kernels */
     int32_t grid = 0, block = 0, maxw = 0, per_cu = 0, wg_frames = 1;   /* wg_frames: frames per one-wave workgroup (z <= 32) */
     size_t lds_bytes = 0;
 };
@@ -575,8 +754,11 @@ inline LdspKernel ldsp_kernel_for(int maxw) { return maxw <= 8 ? layered_ldsp_ke
  * only, last entry of that layer's rows, not an information column), lay the others out in LDS,
  * size the persistent grid and allocate its record rings.  eligible = false (and hipSuccess)
  * when the code does not fit this kernel. */
+inline LdspKernel flood_ldsp_kernel_for(int maxw) { return maxw <= 8 ? flood_ldsp_kernel<8> : flood_ldsp_kernel<16>; }
+
 inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E, const std::vector<int32_t> &row_ptr,
-                                   const std::vector<int32_t> &cols, int32_t z, int32_t K, int64_t max_batch, int device)
+                                   const std::vector<int32_t> &cols, int32_t z, int32_t K, int64_t max_batch, int device,
+                                   bool flood = false)
 {
     std::vector<int32_t> lp, bc, sh, e0;
     pl->eligible = false;
@@ -588,7 +770,7 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
     std::vector<int32_t> deg(nb, 0);
     for (int32_t b : bc) ++deg[b];
     const char *ee = getenv("LDPC_TUNE_LDSP_EXT");
-    const bool allow_ext = !(ee && atoi(ee) == 0);
+    const bool allow_ext = !(ee && atoi(ee) == 0) && !flood;   /* the flooding kernel keeps every column in LDS */
     std::vector<int32_t> slot(nb, 0), hdr((size_t)layers * 4, 0), pack((size_t)layers * 2 * kLdspMaxDeg, 0);
     std::vector<char> external(nb, 0);
     int ext_cols = 0;
@@ -617,11 +799,13 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
         const char *pe = getenv("LDPC_TUNE_LDSP_PACK");
         if (mw == 1 && z <= 32 && !(pe && atoi(pe) == 0)) frames_per_wg = 64 / z;
     }
-    const size_t frame_bytes = ((((size_t)lds_cols * z + 1) & ~(size_t)1)) * sizeof(float);
+    if (flood) frames_per_wg = 1;
+    const size_t frame_bytes = ((((size_t)lds_cols * z + 1) & ~(size_t)1)) * sizeof(float) * (flood ? 2 : 1);   /* flooding: old and new image */
     while (frames_per_wg > 1 && frames_per_wg * frame_bytes + (size_t)layers * sizeof(uint64_t) + 8 > 60 * 1024) --frames_per_wg;
     const size_t lds_bytes = frames_per_wg * frame_bytes + (size_t)layers * mw * sizeof(uint64_t) + 8;
     if (lds_bytes > kLdspMaxLds || lds_cols >= 32768) return hipSuccess;
     pl->wg_frames = frames_per_wg;
+    pl->flood = flood;
     pl->z = z; pl->layers = layers; pl->N = N; pl->E = (int32_t)E; pl->M = M; pl->nb = nb;
     pl->lds_cols = lds_cols; pl->ext_cols = ext_cols; pl->lds_bytes = lds_bytes;
     pl->maxw = mw <= 8 ? 8 : 16;
@@ -634,7 +818,8 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
     hipError_t e;
     if ((e = up(&pl->hdr, hdr)) || (e = up(&pl->pack, pack)) || (e = up(&pl->col_slot, slot)) || (e = up(&pl->layer_e0, e0)))
         return e;
-    const void *k = pl->wg_frames > 1 ? (const void *)layered_ldsp_packed_kernel : (const void *)ldsp_kernel_for(pl->maxw);
+    const void *k = flood ? (const void *)flood_ldsp_kernel_for(mw <= 8 ? 8 : 16)
+                    : pl->wg_frames > 1 ? (const void *)layered_ldsp_packed_kernel : (const void *)ldsp_kernel_for(mw <= 8 ? 8 : 16);
     /* the attribute belongs to the function, not to this plan: always the maximum, so that decoders
      * of different codes can coexist */
     if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdspMaxLds))) return e;
@@ -672,7 +857,8 @@ inline hipError_t ldsp_run(LdspPlan *pl, const FusedRun &r, hipStream_t s, int32
                r.max_iter, rounds, r.early_term};
     const unsigned grid = (unsigned)std::min<int64_t>((r.frames + pl->wg_frames - 1) / pl->wg_frames, pl->grid);
     if (!pl->eligible || grid == 0) return hipErrorInvalidValue;
-    if (pl->wg_frames > 1) layered_ldsp_packed_kernel<<<grid, 64, pl->lds_bytes, s>>>(a, pl->wg_frames);
+    if (pl->flood) flood_ldsp_kernel_for(pl->maxw)<<<grid, pl->block, pl->lds_bytes, s>>>(a);
+    else if (pl->wg_frames > 1) layered_ldsp_packed_kernel<<<grid, 64, pl->lds_bytes, s>>>(a, pl->wg_frames);
     else ldsp_kernel_for(pl->maxw)<<<grid, pl->block, pl->lds_bytes, s>>>(a);
     *launched = rounds;
     return hipGetLastError();

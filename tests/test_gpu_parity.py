@@ -153,8 +153,12 @@ def test_min_sum_fused_and_streaming_paths_agree(built, monkeypatch):
         g, og, K, M, z = _graph(rate, N)
         y = channel.awgn_frames(N, 0, B, sigma, seed=15)
         want = oracle.decode(og, y, "ms", tap_iter=2)
-        for fused in ("1", "0"):
-            monkeypatch.setenv("LDPC_TUNE_FUSED", fused)
+        # "ldsp": posteriors in LDS, one 16-byte record per check row (flood_ldsp_kernel), a grid of 4
+        # persistent workgroups so that each one walks over several frames
+        for fused in ("1", "ldsp", "0"):
+            monkeypatch.setenv("LDPC_TUNE_FUSED", "1" if fused == "ldsp" else fused)
+            monkeypatch.setenv("LDPC_TUNE_LDSP", "1" if fused == "ldsp" else "0")
+            monkeypatch.setenv("LDPC_TUNE_LDSP_GRID", "4")
             dec = L.Decoder(g, K, max_batch=B, algo="ms", layer_rows=z)
             out, iters = dec.decode(y)
             assert np.array_equal(out, want["out"]) and np.array_equal(iters, want["iters"]), (rate, N, fused)
@@ -251,7 +255,7 @@ def test_degenerate_channel_values(built, algo, monkeypatch):
     y[9, :] = -1.0
     y[10, rng.choice(N, 300, replace=False)] *= 400.0             # magnitudes beyond the 1000 clip
     y[11, ::2] = 0.0
-    for fused in (("1",) if algo == "ms_fused" else (("1", "ldsp", "0") if algo == "layered" else ("1", "0"))):
+    for fused in (("1",) if algo == "ms_fused" else (("1", "ldsp", "0") if algo in ("layered", "ms") else ("1", "0"))):
         monkeypatch.setenv("LDPC_TUNE_FUSED", "1" if fused == "ldsp" else fused)
         monkeypatch.setenv("LDPC_TUNE_LDSP", "1" if fused == "ldsp" else "0")
         dec = L.Decoder(g, K, max_batch=24, algo=algo, max_iter=15, layer_rows=z)
@@ -589,4 +593,11 @@ def test_layered_on_random_quasi_cyclic_codes(built, monkeypatch):
             out, iters = dec.decode(y)
             assert np.array_equal(out.reshape(B, kb)[ok], want["out"].reshape(B, kb)[ok]), (z, base.shape, K, mode)
             assert np.array_equal(iters[ok], want["iters"][ok]), (z, base.shape, K, mode)
+            dec.close()
+            # flooding min-sum on the same structures (LDS-resident / record kernel / streaming)
+            if mode == "fused":
+                want_ms = oracle.decode(og, y, "ms", max_iter=9)
+            dec = L.Decoder(g, K, max_batch=B, algo="ms", layer_rows=z, max_iter=9)
+            out, iters = dec.decode(y)
+            assert np.array_equal(out, want_ms["out"]) and np.array_equal(iters, want_ms["iters"]), (z, base.shape, K, mode, "ms")
             dec.close()

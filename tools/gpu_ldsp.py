@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BG1-profile layered decoding at a given lifting size: layered_ldsp_kernel (posterior in LDS,
 check records in cache) against the one-launch-per-layer streaming kernels.
-usage: gpu_ldsp.py Z B sigma [iters] [early_term] [modes]      modes: comma list of ldsp,stream"""
+usage: gpu_ldsp.py Z B sigma [iters] [early_term] [modes] [algo]      modes: comma list of ldsp,stream; algo: layered | ms"""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
@@ -11,6 +11,7 @@ Z, B, sigma = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 early = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 modes = sys.argv[6].split(",") if len(sys.argv) > 6 else ["ldsp", "stream"]
+algo = sys.argv[7] if len(sys.argv) > 7 else "layered"
 rows, cols = codes.nr_bg1_profile_edges(Z)
 N, K, M = 68 * Z, 22 * Z, 46 * Z
 g = L.Graph(rows, cols, M, N)
@@ -22,7 +23,7 @@ ref = None
 for mode in modes:
     os.environ["LDPC_TUNE_LDSP"] = "1" if mode == "ldsp" else "0"
     os.environ["LDPC_TUNE_FUSED"] = "1" if mode == "ldsp" else "0"
-    dec = L.Decoder(g, K, max_batch=B, algo="layered", layer_rows=Z, max_iter=iters, early_term=early)
+    dec = L.Decoder(g, K, max_batch=B, algo=algo, layer_rows=Z, max_iter=iters, early_term=early)
     for _ in range(2):
         dec.decode_device(y.data_ptr(), B, out.data_ptr(), out.numel(), it.data_ptr(), None)
     torch.cuda.synchronize()
@@ -34,7 +35,7 @@ for mode in modes:
     dt = (time.perf_counter() - t0) / reps
     st = dec.stats()
     avg = it.float().mean().item()
-    print("Z=%d N=%d E=%d B=%d sigma=%.2f %s: %.3f ms, %.1f Mbit/s info, avg iters %.2f, converged %d/%d, %.1f G edge-iterations/s" % (
+    print(algo + " Z=%d N=%d E=%d B=%d sigma=%.2f %s: %.3f ms, %.1f Mbit/s info, avg iters %.2f, converged %d/%d, %.1f G edge-iterations/s" % (
         Z, N, len(rows), B, sigma, mode, dt * 1e3, B * K / dt / 1e6, avg, st["frames_converged"], B,
         B * avg * len(rows) / dt / 1e9), flush=True)
     res = (out.clone(), it.clone())
