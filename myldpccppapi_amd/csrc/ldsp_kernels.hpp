@@ -724,6 +724,116 @@ void flood_ldsp_kernel(const LdspArgs a)
     }
 }
 
+
+/* flood_ldsp_kernel for circulants of <= 32 rows: G = 64 / z frames per wave, one wave per
+ * workgroup (see layered_ldsp_packed_kernel). */
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LDPC_LDSP_WAVES_PER_EU)))
+void flood_ldsp_packed_kernel(const LdspArgs a, const int G)
+{
+    extern __shared__ float lds[];
+    const int lane = (int)threadIdx.x;
+    const int z = a.z;
+    const int g = lane / z, r = lane - g * z;
+    const bool member = g < G;
+    const size_t image = ((size_t)a.N + 1) & ~(size_t)1;
+    float *Pa = lds + (size_t)(member ? g : 0) * 2 * image, *Pb = Pa + image;
+    uint4 *recs = a.recs + ((size_t)blockIdx.x * G + (member ? g : 0)) * ((size_t)a.layers * z) + r;
+    const ldpc_const_i32 hdr = as_constant(a.hdr), pack = as_constant(a.pack);
+    const uint64_t gmask = (z >= 64 ? ~0ull : ((1ull << z) - 1ull)) << (member ? g * z : 0);
+    for (int64_t frame0 = (int64_t)blockIdx.x * G; frame0 < a.frames; frame0 += (int64_t)gridDim.x * G) {
+        const int64_t frame = frame0 + g;
+        const bool mine = member && frame < a.frames;
+        const float *y = a.llr + (size_t)(mine ? frame : 0) * a.N;
+        if (mine)
+            for (int n = r; n < a.N; n += z) Pa[n] = y[n];
+        int time = 0, my_iters = a.max_iter;
+        bool active = mine, clean = false;
+        uint4 cur = uint4{0u, 0u, 0u, 0u};
+        while (__ballot(active) != 0ull) {
+            if (active)
+                for (int n = r; n < a.N; n += z) Pb[n] = y[n];
+            lds_barrier();
+            uint64_t last_bad = 0;
+            for (int l = 0; l < a.layers; ++l) {
+                const int ln = l + 1 < a.layers ? l + 1 : 0;
+                uint4 nxt = uint4{0u, 0u, 0u, 0u};
+                if (active && a.layers > 1 && (time > 0 || ln == 0)) nxt = recs[(size_t)ln * z];
+                const int d = hdr[l * 4];
+                const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
+                if (active) {
+                    uint4 rec = cur;
+                    uint64_t pm = 0;
+                    switch (d) {
+#define LDPC_LDSP_CASE(D) case D: ldsp_flood_row<D>(Pa, Pb, pk, z, r, cur, &rec, &pm); break;
+                        LDPC_LDSP_WIDTHS1(LDPC_LDSP_CASE)
+#undef LDPC_LDSP_CASE
+                    default: break;
+                    }
+                    last_bad = pm;
+                    asm volatile("" : "+v"(nxt.x), "+v"(nxt.y), "+v"(nxt.z), "+v"(nxt.w) : : "memory");
+                    recs[(size_t)l * z] = rec;
+                    if (a.layers == 1) nxt = rec;
+                }
+                lds_barrier();
+                cur = nxt;
+            }
+            ++time;
+            const bool check = a.early_term || time == a.rounds;
+            bool any_bad = true;
+            const bool need = active && check && (last_bad & gmask) == 0ull;
+            if (__ballot(need) != 0ull) {
+                uint64_t bad = 0;
+                if (need) {
+                    for (int l = 0; l < a.layers; ++l) {
+                        const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
+                        switch (hdr[l * 4]) {
+#define LDPC_LDSP_CASE(D) case D: bad |= ldsp_flood_parity<D>(Pb, pk, z, r); break;
+                            LDPC_LDSP_WIDTHS1(LDPC_LDSP_CASE)
+#undef LDPC_LDSP_CASE
+                        default: break;
+                        }
+                    }
+                    any_bad = (bad & gmask) != 0ull;
+                }
+            }
+            if (active) {
+                clean = check && !any_bad;
+                float *t = Pa; Pa = Pb; Pb = t;
+                if ((clean && a.early_term) || time == a.rounds) {
+                    active = false;
+                    my_iters = clean ? time : a.max_iter;
+                }
+            }
+            lds_barrier();
+        }
+        if (mine) {
+            const int64_t base = frame * (int64_t)a.K / 8;
+            for (int j = r; j < a.K / 8; j += z) {
+                unsigned byte = 0;
+#pragma unroll
+                for (int bit = 0; bit < 8; ++bit) byte |= (!(Pa[j * 8 + bit] > 0.0f) ? 1u : 0u) << bit;
+                if (base + j < a.out_bytes) a.out[base + j] = (uint8_t)byte;
+            }
+            if (a.dump_p)
+                for (int n = r; n < a.N; n += z) a.dump_p[(size_t)frame * a.N + n] = Pa[n];
+            if (a.dump_r) {
+                for (int l = 0; l < a.layers; ++l) {
+                    const int d = hdr[l * 4], e0 = a.layer_e0[l];
+                    const uint4 rec = recs[(size_t)l * z];
+                    for (int k = 0; k < d; ++k)
+                        a.dump_r[(size_t)frame * a.E + e0 + r * d + k] = __uint_as_float(ldsp_old_message(rec, 0u, k, d));
+                }
+            }
+            if (r == 0) {
+                if (a.iters) a.iters[frame] = my_iters;
+                atomicMax(&a.summary[0], my_iters);
+                if (clean) atomicAdd(&a.summary[1], 1);
+            }
+        }
+        lds_barrier();
+    }
+}
+
 /* ---------------------------------------------------------------- host side */
 
 struct LdspPlan {
@@ -799,7 +909,6 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
         const char *pe = getenv("LDPC_TUNE_LDSP_PACK");
         if (mw == 1 && z <= 32 && !(pe && atoi(pe) == 0)) frames_per_wg = 64 / z;
     }
-    if (flood) frames_per_wg = 1;
     const size_t frame_bytes = ((((size_t)lds_cols * z + 1) & ~(size_t)1)) * sizeof(float) * (flood ? 2 : 1);   /* flooding: old and new image */
     while (frames_per_wg > 1 && frames_per_wg * frame_bytes + (size_t)layers * sizeof(uint64_t) + 8 > 60 * 1024) --frames_per_wg;
     const size_t lds_bytes = frames_per_wg * frame_bytes + (size_t)layers * mw * sizeof(uint64_t) + 8;
@@ -818,7 +927,7 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
     hipError_t e;
     if ((e = up(&pl->hdr, hdr)) || (e = up(&pl->pack, pack)) || (e = up(&pl->col_slot, slot)) || (e = up(&pl->layer_e0, e0)))
         return e;
-    const void *k = flood ? (const void *)flood_ldsp_kernel_for(mw <= 8 ? 8 : 16)
+    const void *k = flood ? (pl->wg_frames > 1 ? (const void *)flood_ldsp_packed_kernel : (const void *)flood_ldsp_kernel_for(mw <= 8 ? 8 : 16))
                     : pl->wg_frames > 1 ? (const void *)layered_ldsp_packed_kernel : (const void *)ldsp_kernel_for(mw <= 8 ? 8 : 16);
     /* the attribute belongs to the function, not to this plan: always the maximum, so that decoders
      * of different codes can coexist */
@@ -857,7 +966,8 @@ inline hipError_t ldsp_run(LdspPlan *pl, const FusedRun &r, hipStream_t s, int32
                r.max_iter, rounds, r.early_term};
     const unsigned grid = (unsigned)std::min<int64_t>((r.frames + pl->wg_frames - 1) / pl->wg_frames, pl->grid);
     if (!pl->eligible || grid == 0) return hipErrorInvalidValue;
-    if (pl->flood) flood_ldsp_kernel_for(pl->maxw)<<<grid, pl->block, pl->lds_bytes, s>>>(a);
+    if (pl->flood && pl->wg_frames > 1) flood_ldsp_packed_kernel<<<grid, 64, pl->lds_bytes, s>>>(a, pl->wg_frames);
+    else if (pl->flood) flood_ldsp_kernel_for(pl->maxw)<<<grid, pl->block, pl->lds_bytes, s>>>(a);
     else if (pl->wg_frames > 1) layered_ldsp_packed_kernel<<<grid, 64, pl->lds_bytes, s>>>(a, pl->wg_frames);
     else ldsp_kernel_for(pl->maxw)<<<grid, pl->block, pl->lds_bytes, s>>>(a);
     *launched = rounds;
