@@ -831,7 +831,9 @@ inline hipError_t fused_plan_create(FusedPlan *pl, int32_t M, int32_t N, int64_t
     pl->max_col_deg = 0;
     for (int b = 0; b < nb; ++b) pl->max_col_deg = std::max(pl->max_col_deg, cp[b + 1] - cp[b]);
     pl->lds_sp = (size_t)(N + 2 * E) * 4 + (((size_t)N + 3) & ~(size_t)3);
-    pl->eligible_sp = pl->max_deg <= 24 && pl->max_col_deg <= 8 && pl->lds_sp <= kFusedMaxLdsPerFrame;
+    /* sum-product keeps Q and R (2 E floats): up to 96 KB per frame, e.g. (2304, 1152) = 70 KB, two
+     * frames per CU -- for the small batches this path serves, latency counts, not occupancy */
+    pl->eligible_sp = pl->max_deg <= 24 && pl->max_col_deg <= 8 && pl->lds_sp <= 96 * 1024;
     pl->eligible = true;
     return hipSuccess;
 }
@@ -892,7 +894,13 @@ inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int
 #define LDPC_COMMA ,
     if (r.flooding == 3) {
         switch (mw * 100 + dm) {
-#define LDPC_SP_CASE(MWV, DMV) case MWV * 100 + DMV: fused_sp_kernel<MWV, DMV, 8><<<grid, 64 * MWV, pl->lds_sp, s>>>(a); break
+#define LDPC_SP_CASE(MWV, DMV) case MWV * 100 + DMV:                                                                     \
+        if (pl->lds_sp > 60 * 1024 &&                                                                                   \
+            (e = hipFuncSetAttribute((const void *)fused_sp_kernel<MWV, DMV, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                     96 * 1024)))                                                                       \
+            return e;                                                                                                   \
+        fused_sp_kernel<MWV, DMV, 8><<<grid, 64 * MWV, pl->lds_sp, s>>>(a);                                             \
+        break
             LDPC_SP_CASE(1, 8); LDPC_SP_CASE(1, 16); LDPC_SP_CASE(1, 24);
             LDPC_SP_CASE(2, 8); LDPC_SP_CASE(2, 16); LDPC_SP_CASE(2, 24);
             LDPC_SP_CASE(3, 8); LDPC_SP_CASE(3, 16); LDPC_SP_CASE(3, 24);
