@@ -758,16 +758,15 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
                 HIP_TRY(ldpc::fused_plan_create(&d->fused, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows));
                 d->use_fused = d->fused.eligible && (cfg->algo == LDPC_ALGO_MS || d->fused.eligible_sp);
             }
-            /* min-sum: posteriors in LDS, one 16-byte record per check row (flood_ldsp_kernel).  Default
-             * wherever its two posterior images leave room for >= 4 workgroups per CU (every 802.16e
-             * size): 2-2.9x the LDS-resident kernel and the streaming kernels at any batch size
-             * ((2304, 1152): 9.9 / 4.0 / 2.9 Gbit/s at 16 384 frames, 2.6 / 0.9 / 1.3 at full work); larger
-             * codes (BG1 Z >= 128: 2 workgroups per CU) only match the streaming kernels and keep them.
-             * LDPC_TUNE_LDSP=1 / 0 forces / forbids it. */
+            /* min-sum: posteriors in LDS (two images), one 16-byte record per check row (flood_ldsp_kernel).
+             * Default wherever it fits with >= 2 workgroups per CU: 2-2.9x the LDS-resident kernel and the
+             * streaming kernels on the 802.16e codes at any batch size ((2304, 1152): 9.9 / 4.0 / 2.9 Gbit/s
+             * at 16 384 frames, 2.6 / 0.9 / 1.3 at full work), 2.4 / 2.0 / 1.7 / 1.2x the streaming kernels on
+             * BG1-profile codes at Z = 64 / 128 / 256 / 384.  LDPC_TUNE_LDSP=1 / 0 forces / forbids it. */
             if (cfg->algo == LDPC_ALGO_MS && !(fe && atoi(fe) == 0) && !(le && atoi(le) == 0)) {
                 HIP_TRY(ldpc::ldsp_plan_create(&d->ldsp, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows,
                                                cfg->K, cfg->max_batch, cfg->device, /*flood=*/true));
-                if (d->ldsp.eligible && ((le && atoi(le) != 0) || d->ldsp.lds_bytes <= 40 * 1024))
+                if (d->ldsp.eligible && ((le && atoi(le) != 0) || d->ldsp.lds_bytes <= 80 * 1024))
                     d->use_fused = d->use_ldsp = true;
                 else
                     ldpc::ldsp_plan_destroy(&d->ldsp);

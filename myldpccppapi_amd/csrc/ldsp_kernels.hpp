@@ -556,14 +556,17 @@ void layered_ldsp_packed_kernel(const LdspArgs a, const int G)
  * NEW posteriors, which start from the channel values: two LDS images, layers in ascending order
  * with a barrier in between, so that every column receives y + R_1 + R_2 + ... in ascending row
  * order as refreshPostPMS computes it.  Hard decision !(p > 0), syndrome, stop when clean. */
-template <int D>
+template <int DL, int EXT>
 __device__ __forceinline__ void ldsp_flood_row(const float *Pold, float *Pnew, ldpc_const_i32 pk, int z, int r,
-                                               const uint4 old, uint4 *out, uint64_t *par_mask)
+                                               const uint4 old, float pext_old, float yext, uint4 *out,
+                                               uint64_t *par_mask, uint64_t *ext_mask)
 {
+    constexpr int D = DL + EXT;
+    constexpr int DLA = DL > 0 ? DL : 1;
     float q[D];
-    uint32_t off[D];
+    uint32_t off[DLA];
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
+    for (int k = 0; k < DL; ++k) {
         const uint32_t t = (uint32_t)(r * 4) + (uint32_t)pk[kLdspMaxDeg + k];
         const uint32_t tw = t - (uint32_t)(z * 4);
         off[k] = (t < tw ? t : tw) + (uint32_t)pk[k];
@@ -573,7 +576,9 @@ __device__ __forceinline__ void ldsp_flood_row(const float *Pold, float *Pnew, l
     for (int k = 0; k < D; ++k) {
         const uint32_t sel = (k == oidx) ? old.y : old.x;
         const uint32_t rold = ((old.z << (31 - (D - 1 - k))) & 0x80000000u) | sel;
-        q[k] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(Pold) + off[k]) - __uint_as_float(rold);
+        const float pin = k < DL ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(Pold) + off[k < DL ? k : 0])
+                                 : pext_old;
+        q[k] = pin - __uint_as_float(rold);
     }
     float m1 = 1000.0f, m2 = 1000.0f;
     int idx = 31;                                                   /* none */
@@ -589,18 +594,25 @@ __device__ __forceinline__ void ldsp_flood_row(const float *Pold, float *Pnew, l
         idx = lt1 ? k : idx;
     }
     const uint32_t b1 = __float_as_uint(m1), b2 = __float_as_uint(m2);
-    uint32_t signs = 0;
+    uint32_t signs = 0, pext = 0;
     uint64_t pm = 0;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         const uint32_t rn = ((k == idx) ? b2 : b1) ^ (par ^ neg[k]);    /* s ? -b : b, b >= 0 */
-        float *p = reinterpret_cast<float *>(reinterpret_cast<char *>(Pnew) + off[k]);
-        const float pn = *p + __uint_as_float(rn);
-        *p = pn;
+        float pn;
+        if (k < DL) {
+            float *p = reinterpret_cast<float *>(reinterpret_cast<char *>(Pnew) + off[k < DL ? k : 0]);
+            pn = *p + __uint_as_float(rn);
+            *p = pn;
+        } else {
+            pn = yext + __uint_as_float(rn);                        /* a single-layer column: y + its one message */
+            pext = __float_as_uint(pn);
+            *ext_mask = __ballot(!(pn > 0.0f));
+        }
         signs = __builtin_amdgcn_alignbit(signs, rn, 31);
         pm ^= __ballot(!(pn > 0.0f));
     }
-    *out = uint4{b1, b2, signs | ((uint32_t)idx << 24), 0u};
+    *out = uint4{b1, b2, signs | ((uint32_t)idx << 24), pext};
     *par_mask = pm;
 }
 
@@ -624,14 +636,15 @@ __global__ __launch_bounds__(64 * MAXW) __attribute__((amdgpu_waves_per_eu(LDPC_
 void flood_ldsp_kernel(const LdspArgs a)
 {
     extern __shared__ float lds[];
-    const int r = (int)threadIdx.x, LANES = (int)blockDim.x;
+    const int r = (int)threadIdx.x, LANES = (int)blockDim.x, MW = LANES >> 6, wave = r >> 6;
     const int z = a.z;
-    const size_t image = ((size_t)a.N + 1) & ~(size_t)1;
-    float *Pa = lds, *Pb = lds + image;                             /* old / new posteriors, [N] each */
-    uint32_t *wg_flag = reinterpret_cast<uint32_t *>(lds + 2 * image);
+    const size_t image = ((size_t)a.lds_cols * z + 1) & ~(size_t)1;
+    float *Pa = lds, *Pb = lds + image;                             /* old / new posteriors, [lds_cols][z] each */
+    uint64_t *extneg = reinterpret_cast<uint64_t *>(lds + 2 * image);   /* [layers][MW] */
+    uint32_t *wg_flag = reinterpret_cast<uint32_t *>(extneg + (size_t)a.layers * MW);
     const bool row = r < z;
     uint4 *recs = a.recs + (size_t)blockIdx.x * ((size_t)a.layers * z) + r;
-    const ldpc_const_i32 hdr = as_constant(a.hdr), pack = as_constant(a.pack);
+    const ldpc_const_i32 hdr = as_constant(a.hdr), pack = as_constant(a.pack), cslot = as_constant(a.col_slot);
     auto wg_any = [&](bool pred) {
         if (r == 0) *wg_flag = 0u;
         lds_barrier();
@@ -641,30 +654,50 @@ void flood_ldsp_kernel(const LdspArgs a)
         lds_barrier();
         return f != 0u;
     };
+    auto fill = [&](float *P, const float *y) {                    /* the LDS-resident columns' channel values */
+        if (row)
+            for (int bc = 0; bc < a.nb; ++bc) {
+                const int slot = cslot[bc];
+                if (slot >= 0) P[slot * z + r] = y[bc * z + r];
+            }
+    };
     for (int64_t frame = blockIdx.x; frame < a.frames; frame += gridDim.x) {
         const float *y = a.llr + (size_t)frame * a.N;
-        for (int n = r; n < a.N; n += LANES) Pa[n] = y[n];         /* Q_0 = y: P_0 = y, R_0 = 0 */
+        fill(Pa, y);                                               /* Q_0 = y: P_0 = y, R_0 = 0 */
         int time = 0;
         bool clean = false;
         uint4 cur = uint4{0u, 0u, 0u, 0u};
         while (true) {
-            for (int n = r; n < a.N; n += LANES) Pb[n] = y[n];     /* refreshPostPMS starts from the channel value */
+            fill(Pb, y);                                           /* refreshPostPMS starts from the channel value */
             __syncthreads();
             uint64_t last_bad = 0;
             for (int l = 0; l < a.layers; ++l) {
                 const int ln = l + 1 < a.layers ? l + 1 : 0;
                 uint4 nxt = uint4{0u, 0u, 0u, 0u};
                 if (row && a.layers > 1 && (time > 0 || ln == 0)) nxt = recs[(size_t)ln * z];
-                const int d = hdr[l * 4];
+                const int dl = hdr[l * 4], ext = hdr[l * 4 + 1];
                 const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
                 if (row) {
+                    float yext = 0.0f;
+                    if (ext) yext = y[hdr[l * 4 + 2] + ldsp_wrap(r, hdr[l * 4 + 3], z)];
+                    const float pext_old = time == 0 ? yext : __uint_as_float(cur.w);
                     uint4 rec = cur;
-                    uint64_t pm = 0;
-                    switch (d) {
-#define LDPC_LDSP_CASE(D) case D: ldsp_flood_row<D>(Pa, Pb, pk, z, r, cur, &rec, &pm); break;
-                        LDPC_LDSP_WIDTHS1(LDPC_LDSP_CASE)
+                    uint64_t pm = 0, em = 0;
+                    if (ext) {
+                        switch (dl) {
+#define LDPC_LDSP_CASE(D) case D: ldsp_flood_row<D, 1>(Pa, Pb, pk, z, r, cur, pext_old, yext, &rec, &pm, &em); break;
+                            LDPC_LDSP_WIDTHS(LDPC_LDSP_CASE)
 #undef LDPC_LDSP_CASE
-                    default: break;
+                        default: break;
+                        }
+                        if ((r & 63) == 0) extneg[l * MW + wave] = em;
+                    } else {
+                        switch (dl) {
+#define LDPC_LDSP_CASE(D) case D + 1: ldsp_flood_row<D + 1, 0>(Pa, Pb, pk, z, r, cur, 0.0f, 0.0f, &rec, &pm, &em); break;
+                            LDPC_LDSP_WIDTHS(LDPC_LDSP_CASE)
+#undef LDPC_LDSP_CASE
+                        default: break;
+                        }
                     }
                     last_bad = pm;
                     asm volatile("" : "+v"(nxt.x), "+v"(nxt.y), "+v"(nxt.z), "+v"(nxt.w) : : "memory");
@@ -682,12 +715,15 @@ void flood_ldsp_kernel(const LdspArgs a)
                 if (row) {
                     for (int l = 0; l < a.layers; ++l) {
                         const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
+                        uint64_t par = 0;
                         switch (hdr[l * 4]) {
-#define LDPC_LDSP_CASE(D) case D: bad |= ldsp_flood_parity<D>(Pb, pk, z, r); break;
+#define LDPC_LDSP_CASE(D) case D: par = ldsp_flood_parity<D>(Pb, pk, z, r); break;
                             LDPC_LDSP_WIDTHS1(LDPC_LDSP_CASE)
 #undef LDPC_LDSP_CASE
                         default: break;
                         }
+                        if (hdr[l * 4 + 1]) par ^= extneg[l * MW + wave];
+                        bad |= par;
                     }
                 }
                 any_bad = wg_any(bad != 0ull) ? 1 : 0;
@@ -696,7 +732,7 @@ void flood_ldsp_kernel(const LdspArgs a)
             float *t = Pa; Pa = Pb; Pb = t;                         /* the new posteriors are the next round's old ones */
             if ((clean && a.early_term) || time == a.rounds) break;
         }
-        /* Pa holds the final posteriors */
+        /* Pa holds the final posteriors; the information columns sit at slot = block column */
         const int64_t base = frame * (int64_t)a.K / 8;
         for (int j = r; j < a.K / 8; j += LANES) {
             unsigned byte = 0;
@@ -704,11 +740,19 @@ void flood_ldsp_kernel(const LdspArgs a)
             for (int bit = 0; bit < 8; ++bit) byte |= (!(Pa[j * 8 + bit] > 0.0f) ? 1u : 0u) << bit;
             if (base + j < a.out_bytes) a.out[base + j] = (uint8_t)byte;
         }
-        if (a.dump_p)
-            for (int n = r; n < a.N; n += LANES) a.dump_p[(size_t)frame * a.N + n] = Pa[n];
+        if (a.dump_p && row) {
+            for (int bc = 0; bc < a.nb; ++bc) {
+                const int slot = cslot[bc];
+                if (slot >= 0) a.dump_p[(size_t)frame * a.N + bc * z + r] = Pa[slot * z + r];
+            }
+            for (int l = 0; l < a.layers; ++l)
+                if (hdr[l * 4 + 1])
+                    a.dump_p[(size_t)frame * a.N + hdr[l * 4 + 2] + ldsp_wrap(r, hdr[l * 4 + 3], z)] =
+                        __uint_as_float(recs[(size_t)l * z].w);
+        }
         if (a.dump_r && row) {
             for (int l = 0; l < a.layers; ++l) {
-                const int d = hdr[l * 4], e0 = a.layer_e0[l];
+                const int d = hdr[l * 4] + hdr[l * 4 + 1], e0 = a.layer_e0[l];
                 const uint4 rec = recs[(size_t)l * z];
                 for (int k = 0; k < d; ++k)
                     a.dump_r[(size_t)frame * a.E + e0 + r * d + k] = __uint_as_float(ldsp_old_message(rec, 0u, k, d));
@@ -723,7 +767,6 @@ void flood_ldsp_kernel(const LdspArgs a)
         __syncthreads();
     }
 }
-
 
 /* flood_ldsp_kernel for circulants of <= 32 rows: G = 64 / z frames per wave, one wave per
  * workgroup (see layered_ldsp_packed_kernel). */
@@ -762,9 +805,9 @@ void flood_ldsp_packed_kernel(const LdspArgs a, const int G)
                 const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
                 if (active) {
                     uint4 rec = cur;
-                    uint64_t pm = 0;
+                    uint64_t pm = 0, em = 0;
                     switch (d) {
-#define LDPC_LDSP_CASE(D) case D: ldsp_flood_row<D>(Pa, Pb, pk, z, r, cur, &rec, &pm); break;
+#define LDPC_LDSP_CASE(D) case D: ldsp_flood_row<D, 0>(Pa, Pb, pk, z, r, cur, 0.0f, 0.0f, &rec, &pm, &em); break;
                         LDPC_LDSP_WIDTHS1(LDPC_LDSP_CASE)
 #undef LDPC_LDSP_CASE
                     default: break;
@@ -880,7 +923,9 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
     std::vector<int32_t> deg(nb, 0);
     for (int32_t b : bc) ++deg[b];
     const char *ee = getenv("LDPC_TUNE_LDSP_EXT");
-    const bool allow_ext = !(ee && atoi(ee) == 0) && !flood;   /* the flooding kernel keeps every column in LDS */
+    const char *pe0 = getenv("LDPC_TUNE_LDSP_PACK");
+    const bool will_pack = z <= 32 && !(pe0 && atoi(pe0) == 0);
+    const bool allow_ext = !(ee && atoi(ee) == 0) && !(flood && will_pack);   /* the packed flooding kernel keeps every column in LDS */
     std::vector<int32_t> slot(nb, 0), hdr((size_t)layers * 4, 0), pack((size_t)layers * 2 * kLdspMaxDeg, 0);
     std::vector<char> external(nb, 0);
     int ext_cols = 0;
