@@ -709,10 +709,21 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     if (cfg->algo == LDPC_ALGO_MS_FUSED) {
         if (cfg->pack_mode != LDPC_PACK_BYTES && cfg->K % 8)
             return fail(LDPC_ERR_UNSUPPORTED, "MS_FUSED packs whole bytes per frame only");
-        HIP_TRY(ldpc::fused_plan_create(&d->fused, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows));
-        if (!d->fused.eligible)
-            return fail(LDPC_ERR_UNSUPPORTED, "MS_FUSED needs a quasi-cyclic H with circulant size "
-                        "layer_rows <= 256 and (N+E)*4 B <= %zu B of LDS per frame", ldpc::kFusedMaxLdsPerFrame);
+        /* flood_ldsp_kernel<.., CHAIN = false> (posteriors in LDS, 16-byte check records) wherever it fits
+         * with two workgroups per CU, else / with LDPC_TUNE_LDSP=0 the LDS-resident fused_flood_kernel */
+        const char *le = getenv("LDPC_TUNE_LDSP");
+        if (!(le && atoi(le) == 0)) {
+            HIP_TRY(ldpc::ldsp_plan_create(&d->ldsp, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows, cfg->K,
+                                           cfg->max_batch, cfg->device, /*flood=*/2));
+            if (d->ldsp.eligible && ((le && atoi(le) != 0) || d->ldsp.lds_bytes <= 80 * 1024)) d->use_ldsp = true;
+            else ldpc::ldsp_plan_destroy(&d->ldsp);
+        }
+        if (!d->use_ldsp) {
+            HIP_TRY(ldpc::fused_plan_create(&d->fused, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows));
+            if (!d->fused.eligible)
+                return fail(LDPC_ERR_UNSUPPORTED, "MS_FUSED needs a quasi-cyclic H (circulant size = layer_rows) whose "
+                            "posteriors fit in LDS");
+        }
         d->use_fused = true;
     } else if (cfg->algo == LDPC_ALGO_LAYERED) {
         /* short quasi-cyclic codes decode entirely in LDS, one launch (fused_kernels.hpp);
@@ -765,7 +776,7 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
              * BG1-profile codes at Z = 64 / 128 / 256 / 384.  LDPC_TUNE_LDSP=1 / 0 forces / forbids it. */
             if (cfg->algo == LDPC_ALGO_MS && !(fe && atoi(fe) == 0) && !(le && atoi(le) == 0)) {
                 HIP_TRY(ldpc::ldsp_plan_create(&d->ldsp, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows,
-                                               cfg->K, cfg->max_batch, cfg->device, /*flood=*/true));
+                                               cfg->K, cfg->max_batch, cfg->device, /*flood=*/1));
                 if (d->ldsp.eligible && ((le && atoi(le) != 0) || d->ldsp.lds_bytes <= 80 * 1024))
                     d->use_fused = d->use_ldsp = true;
                 else
@@ -1012,7 +1023,7 @@ int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t ca
             out[k].degree = sp.degree;
             if (sp.kind == 3) snprintf(out[k].name, sizeof out[k].name, "other");
             else if (d->use_fused)      /* whole decode in one launch; bytes = channel values in + packed bits out */
-                snprintf(out[k].name, sizeof out[k].name, "%s", d->use_ldsp ? (d->cfg.algo == LDPC_ALGO_MS ? "flood_ldsp_kernel" : "layered_ldsp_kernel")
+                snprintf(out[k].name, sizeof out[k].name, "%s", d->use_ldsp ? (d->cfg.algo == LDPC_ALGO_LAYERED ? "layered_ldsp_kernel" : "flood_ldsp_kernel")
                          : d->cfg.algo == LDPC_ALGO_SP ? "fused_sp_kernel"
                          : d->cfg.algo == LDPC_ALGO_LAYERED ? "fused_layered_kernel" : "fused_flood_kernel");
             else snprintf(out[k].name, sizeof out[k].name, "%s<%s,%d,%d>", phase_name[sp.kind],

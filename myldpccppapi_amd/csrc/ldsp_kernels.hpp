@@ -616,7 +616,123 @@ __device__ __forceinline__ void ldsp_flood_row(const float *Pold, float *Pnew, l
     *par_mask = pm;
 }
 
-template <int D>
+/* The same placement with the arithmetic of the reference's fused flooding kernel decodeOnceMS
+ * (DecodeMSCL, decodeCL.c:482-512): product sign and the 1000 / 1001 two-minimum rule with <=, i.e.
+ * the check rule of the layered kernel above (same record format, same irregular slow path), hard
+ * decision P < 0. */
+__device__ __forceinline__ uint4 ldsp_mscl_row_any(const float *Pold, float *Pnew, ldpc_const_i32 pk, int dl, int ext,
+                                                   int z, int r, const uint4 old, float pext_old, float yext,
+                                                   uint32_t *zfp, uint64_t *par_mask, uint64_t *ext_mask)
+{
+    const int d = dl + ext;
+    const uint32_t ozf = (old.z & kLdspIrregular) ? *zfp : 0u;
+    float prod = 1.0f, b = 1000.0f, c = 1001.0f;
+    int bind = 31;
+    for (int k = 0; k < d; ++k) {
+        const float rold = __uint_as_float(ldsp_old_message(old, ozf, k, d));
+        const float pin = k < dl ? *ldsp_at(const_cast<float *>(Pold), pk[k], pk[kLdspMaxDeg + k], r * 4, z * 4) : pext_old;
+        const float q = pin - rold;
+        prod *= q;
+        const float mag = __builtin_fabsf(q);
+        if (mag <= b) { c = b; b = mag; bind = k; }
+        else if (mag > b && mag <= c) { c = mag; }
+    }
+    const float sa = cl_sign(prod);
+    const float ab = sa * b, ac = sa * c;
+    const uint32_t mab = __float_as_uint(ab) & 0x7fffffffu, mac = __float_as_uint(ac) & 0x7fffffffu;
+    uint32_t signs = 0, zf = 0, pext = 0;
+    uint64_t pm = 0;
+    for (int k = 0; k < d; ++k) {
+        const float rold = __uint_as_float(ldsp_old_message(old, ozf, k, d));   /* P_old is untouched: same q again */
+        float *pn_at = k < dl ? ldsp_at(Pnew, pk[k], pk[kLdspMaxDeg + k], r * 4, z * 4) : nullptr;
+        const float pin = k < dl ? *ldsp_at(const_cast<float *>(Pold), pk[k], pk[kLdspMaxDeg + k], r * 4, z * 4) : pext_old;
+        const float q = pin - rold;
+        const float rn = cl_sign(q) * ((k == bind) ? ac : ab);
+        const float pn = (k < dl ? *pn_at : yext) + rn;
+        if (k < dl) *pn_at = pn;
+        else { pext = __float_as_uint(pn); *ext_mask = __ballot(pn < 0.0f); }
+        const uint32_t rb = __float_as_uint(rn);
+        signs = (signs << 1) | (rb >> 31);
+        if ((rb & 0x7fffffffu) != ((k == bind) ? mac : mab)) zf |= 1u << k;
+        pm ^= __ballot(pn < 0.0f);
+    }
+    uint32_t word = signs | ((uint32_t)bind << 24);
+    if (zf) {
+        word |= kLdspIrregular;
+        *zfp = zf;
+    }
+    *par_mask = pm;
+    return uint4{mab, mac, word, pext};
+}
+
+template <int DL, int EXT>
+__device__ __forceinline__ bool ldsp_mscl_row(const float *Pold, float *Pnew, ldpc_const_i32 pk, int z, int r,
+                                              const uint4 old, float pext_old, float yext, uint4 *out,
+                                              uint64_t *par_mask, uint64_t *ext_mask)
+{
+    constexpr int D = DL + EXT;
+    constexpr int DLA = DL > 0 ? DL : 1;
+    if (__ballot((old.z & kLdspIrregular) != 0u) != 0ull) return false;
+    float q[D];
+    uint32_t off[DLA];
+#pragma unroll
+    for (int k = 0; k < DL; ++k) {
+        const uint32_t t = (uint32_t)(r * 4) + (uint32_t)pk[kLdspMaxDeg + k];
+        const uint32_t tw = t - (uint32_t)(z * 4);
+        off[k] = (t < tw ? t : tw) + (uint32_t)pk[k];
+    }
+    const int obind = (int)((old.z >> 24) & 31u);
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const uint32_t sel = (k == obind) ? old.y : old.x;
+        const uint32_t rold = ((old.z << (31 - (D - 1 - k))) & 0x80000000u) | sel;
+        const float pin = k < DL ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(Pold) + off[k < DL ? k : 0])
+                                 : pext_old;
+        q[k] = pin - __uint_as_float(rold);
+    }
+    float prod = 1.0f, b = 1000.0f, c = 1001.0f;
+    int bind = 31;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        prod *= q[k];
+        const float mag = __builtin_fabsf(q[k]);
+        const bool le = mag <= b;
+        bind = le ? k : bind;
+        c = __builtin_amdgcn_fmed3f(b, mag, c);
+        b = __builtin_amdgcn_fmed3f(0.0f, mag, b);
+    }
+    const uint32_t pb = __float_as_uint(prod);
+    if (__ballot(!ldsp_regular(pb)) != 0ull) return false;         /* nothing written yet */
+    const uint32_t ps = pb & 0x80000000u;
+    const uint32_t mb = __float_as_uint(b), mc = __float_as_uint(c);
+    uint32_t signs = 0, pext = 0;
+    uint64_t pm = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const uint32_t sel = (k == bind) ? mc : mb;
+        const uint32_t rn = ((__float_as_uint(q[k]) ^ ps) & 0x80000000u) | sel;
+        float pn;
+        if (k < DL) {
+            float *p = reinterpret_cast<float *>(reinterpret_cast<char *>(Pnew) + off[k < DL ? k : 0]);
+            pn = *p + __uint_as_float(rn);
+            *p = pn;
+        } else {
+            pn = yext + __uint_as_float(rn);
+            pext = __float_as_uint(pn);
+            *ext_mask = __ballot(pn < 0.0f);
+        }
+        signs = __builtin_amdgcn_alignbit(signs, rn, 31);
+        pm ^= __ballot(pn < 0.0f);
+    }
+    *out = uint4{mb, mc, signs | ((uint32_t)bind << 24), pext};
+    *par_mask = pm;
+    return true;
+}
+
+/* hard decision: !(p > 0) in the MS chain (decodeCL.c:161-165), p < 0 in the fused reference kernels (:541) */
+template <bool CHAIN> __device__ __forceinline__ bool ldsp_flood_bit(float p) { return CHAIN ? !(p > 0.0f) : (p < 0.0f); }
+
+template <int D, bool CHAIN>
 __device__ __forceinline__ uint64_t ldsp_flood_parity(const float *P, ldpc_const_i32 pk, int z, int r)
 {
     float v[D];
@@ -624,14 +740,14 @@ __device__ __forceinline__ uint64_t ldsp_flood_parity(const float *P, ldpc_const
     for (int k = 0; k < D; ++k) v[k] = *ldsp_at(const_cast<float *>(P), pk[k], pk[kLdspMaxDeg + k], r * 4, z * 4);
     uint64_t par = 0;
 #pragma unroll
-    for (int k = 0; k < D; ++k) par ^= __ballot(!(v[k] > 0.0f));
+    for (int k = 0; k < D; ++k) par ^= __ballot(ldsp_flood_bit<CHAIN>(v[k]));
     return par;
 }
 
 #define LDPC_LDSP_WIDTHS1(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) \
     X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
 
-template <int MAXW>
+template <int MAXW, bool CHAIN>
 __global__ __launch_bounds__(64 * MAXW) __attribute__((amdgpu_waves_per_eu(LDPC_LDSP_WAVES_PER_EU)))
 void flood_ldsp_kernel(const LdspArgs a)
 {
@@ -644,6 +760,7 @@ void flood_ldsp_kernel(const LdspArgs a)
     uint32_t *wg_flag = reinterpret_cast<uint32_t *>(extneg + (size_t)a.layers * MW);
     const bool row = r < z;
     uint4 *recs = a.recs + (size_t)blockIdx.x * ((size_t)a.layers * z) + r;
+    uint32_t *zfs = a.zf + (size_t)blockIdx.x * ((size_t)a.layers * z) + r;
     const ldpc_const_i32 hdr = as_constant(a.hdr), pack = as_constant(a.pack), cslot = as_constant(a.col_slot);
     auto wg_any = [&](bool pred) {
         if (r == 0) *wg_flag = 0u;
@@ -683,22 +800,31 @@ void flood_ldsp_kernel(const LdspArgs a)
                     const float pext_old = time == 0 ? yext : __uint_as_float(cur.w);
                     uint4 rec = cur;
                     uint64_t pm = 0, em = 0;
+                    bool done = CHAIN;                             /* the chain arithmetic has no slow path */
                     if (ext) {
                         switch (dl) {
-#define LDPC_LDSP_CASE(D) case D: ldsp_flood_row<D, 1>(Pa, Pb, pk, z, r, cur, pext_old, yext, &rec, &pm, &em); break;
+#define LDPC_LDSP_CASE(D) case D:                                                                                  \
+                            if (CHAIN) ldsp_flood_row<D, 1>(Pa, Pb, pk, z, r, cur, pext_old, yext, &rec, &pm, &em);        \
+                            else done = ldsp_mscl_row<D, 1>(Pa, Pb, pk, z, r, cur, pext_old, yext, &rec, &pm, &em);         \
+                            break;
                             LDPC_LDSP_WIDTHS(LDPC_LDSP_CASE)
 #undef LDPC_LDSP_CASE
                         default: break;
                         }
-                        if ((r & 63) == 0) extneg[l * MW + wave] = em;
                     } else {
                         switch (dl) {
-#define LDPC_LDSP_CASE(D) case D + 1: ldsp_flood_row<D + 1, 0>(Pa, Pb, pk, z, r, cur, 0.0f, 0.0f, &rec, &pm, &em); break;
+#define LDPC_LDSP_CASE(D) case D + 1:                                                                              \
+                            if (CHAIN) ldsp_flood_row<D + 1, 0>(Pa, Pb, pk, z, r, cur, 0.0f, 0.0f, &rec, &pm, &em);        \
+                            else done = ldsp_mscl_row<D + 1, 0>(Pa, Pb, pk, z, r, cur, 0.0f, 0.0f, &rec, &pm, &em);         \
+                            break;
                             LDPC_LDSP_WIDTHS(LDPC_LDSP_CASE)
 #undef LDPC_LDSP_CASE
                         default: break;
                         }
                     }
+                    if (!CHAIN && !done)
+                        rec = ldsp_mscl_row_any(Pa, Pb, pk, dl, ext, z, r, cur, pext_old, yext, zfs + (size_t)l * z, &pm, &em);
+                    if (ext && (r & 63) == 0) extneg[l * MW + wave] = em;
                     last_bad = pm;
                     asm volatile("" : "+v"(nxt.x), "+v"(nxt.y), "+v"(nxt.z), "+v"(nxt.w) : : "memory");
                     recs[(size_t)l * z] = rec;
@@ -717,7 +843,7 @@ void flood_ldsp_kernel(const LdspArgs a)
                         const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
                         uint64_t par = 0;
                         switch (hdr[l * 4]) {
-#define LDPC_LDSP_CASE(D) case D: par = ldsp_flood_parity<D>(Pb, pk, z, r); break;
+#define LDPC_LDSP_CASE(D) case D: par = ldsp_flood_parity<D, CHAIN>(Pb, pk, z, r); break;
                             LDPC_LDSP_WIDTHS1(LDPC_LDSP_CASE)
 #undef LDPC_LDSP_CASE
                         default: break;
@@ -737,7 +863,7 @@ void flood_ldsp_kernel(const LdspArgs a)
         for (int j = r; j < a.K / 8; j += LANES) {
             unsigned byte = 0;
 #pragma unroll
-            for (int bit = 0; bit < 8; ++bit) byte |= (!(Pa[j * 8 + bit] > 0.0f) ? 1u : 0u) << bit;
+            for (int bit = 0; bit < 8; ++bit) byte |= (ldsp_flood_bit<CHAIN>(Pa[j * 8 + bit]) ? 1u : 0u) << bit;
             if (base + j < a.out_bytes) a.out[base + j] = (uint8_t)byte;
         }
         if (a.dump_p && row) {
@@ -754,8 +880,9 @@ void flood_ldsp_kernel(const LdspArgs a)
             for (int l = 0; l < a.layers; ++l) {
                 const int d = hdr[l * 4] + hdr[l * 4 + 1], e0 = a.layer_e0[l];
                 const uint4 rec = recs[(size_t)l * z];
+                const uint32_t zf = (rec.z & kLdspIrregular) ? zfs[(size_t)l * z] : 0u;
                 for (int k = 0; k < d; ++k)
-                    a.dump_r[(size_t)frame * a.E + e0 + r * d + k] = __uint_as_float(ldsp_old_message(rec, 0u, k, d));
+                    a.dump_r[(size_t)frame * a.E + e0 + r * d + k] = __uint_as_float(ldsp_old_message(rec, zf, k, d));
             }
         }
         if (r == 0) {
@@ -770,6 +897,7 @@ void flood_ldsp_kernel(const LdspArgs a)
 
 /* flood_ldsp_kernel for circulants of <= 32 rows: G = 64 / z frames per wave, one wave per
  * workgroup (see layered_ldsp_packed_kernel). */
+template <bool CHAIN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LDPC_LDSP_WAVES_PER_EU)))
 void flood_ldsp_packed_kernel(const LdspArgs a, const int G)
 {
@@ -781,6 +909,7 @@ void flood_ldsp_packed_kernel(const LdspArgs a, const int G)
     const size_t image = ((size_t)a.N + 1) & ~(size_t)1;
     float *Pa = lds + (size_t)(member ? g : 0) * 2 * image, *Pb = Pa + image;
     uint4 *recs = a.recs + ((size_t)blockIdx.x * G + (member ? g : 0)) * ((size_t)a.layers * z) + r;
+    uint32_t *zfs = a.zf + ((size_t)blockIdx.x * G + (member ? g : 0)) * ((size_t)a.layers * z) + r;
     const ldpc_const_i32 hdr = as_constant(a.hdr), pack = as_constant(a.pack);
     const uint64_t gmask = (z >= 64 ? ~0ull : ((1ull << z) - 1ull)) << (member ? g * z : 0);
     for (int64_t frame0 = (int64_t)blockIdx.x * G; frame0 < a.frames; frame0 += (int64_t)gridDim.x * G) {
@@ -806,12 +935,18 @@ void flood_ldsp_packed_kernel(const LdspArgs a, const int G)
                 if (active) {
                     uint4 rec = cur;
                     uint64_t pm = 0, em = 0;
+                    bool done = CHAIN;
                     switch (d) {
-#define LDPC_LDSP_CASE(D) case D: ldsp_flood_row<D, 0>(Pa, Pb, pk, z, r, cur, 0.0f, 0.0f, &rec, &pm, &em); break;
+#define LDPC_LDSP_CASE(D) case D:                                                                                  \
+                        if (CHAIN) ldsp_flood_row<D, 0>(Pa, Pb, pk, z, r, cur, 0.0f, 0.0f, &rec, &pm, &em);                \
+                        else done = ldsp_mscl_row<D, 0>(Pa, Pb, pk, z, r, cur, 0.0f, 0.0f, &rec, &pm, &em);                 \
+                        break;
                         LDPC_LDSP_WIDTHS1(LDPC_LDSP_CASE)
 #undef LDPC_LDSP_CASE
                     default: break;
                     }
+                    if (!CHAIN && !done)
+                        rec = ldsp_mscl_row_any(Pa, Pb, pk, d, 0, z, r, cur, 0.0f, 0.0f, zfs + (size_t)l * z, &pm, &em);
                     last_bad = pm;
                     asm volatile("" : "+v"(nxt.x), "+v"(nxt.y), "+v"(nxt.z), "+v"(nxt.w) : : "memory");
                     recs[(size_t)l * z] = rec;
@@ -830,7 +965,7 @@ void flood_ldsp_packed_kernel(const LdspArgs a, const int G)
                     for (int l = 0; l < a.layers; ++l) {
                         const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
                         switch (hdr[l * 4]) {
-#define LDPC_LDSP_CASE(D) case D: bad |= ldsp_flood_parity<D>(Pb, pk, z, r); break;
+#define LDPC_LDSP_CASE(D) case D: bad |= ldsp_flood_parity<D, CHAIN>(Pb, pk, z, r); break;
                             LDPC_LDSP_WIDTHS1(LDPC_LDSP_CASE)
 #undef LDPC_LDSP_CASE
                         default: break;
@@ -854,7 +989,7 @@ void flood_ldsp_packed_kernel(const LdspArgs a, const int G)
             for (int j = r; j < a.K / 8; j += z) {
                 unsigned byte = 0;
 #pragma unroll
-                for (int bit = 0; bit < 8; ++bit) byte |= (!(Pa[j * 8 + bit] > 0.0f) ? 1u : 0u) << bit;
+                for (int bit = 0; bit < 8; ++bit) byte |= (ldsp_flood_bit<CHAIN>(Pa[j * 8 + bit]) ? 1u : 0u) << bit;
                 if (base + j < a.out_bytes) a.out[base + j] = (uint8_t)byte;
             }
             if (a.dump_p)
@@ -863,8 +998,9 @@ void flood_ldsp_packed_kernel(const LdspArgs a, const int G)
                 for (int l = 0; l < a.layers; ++l) {
                     const int d = hdr[l * 4], e0 = a.layer_e0[l];
                     const uint4 rec = recs[(size_t)l * z];
+                    const uint32_t zf = (rec.z & kLdspIrregular) ? zfs[(size_t)l * z] : 0u;
                     for (int k = 0; k < d; ++k)
-                        a.dump_r[(size_t)frame * a.E + e0 + r * d + k] = __uint_as_float(ldsp_old_message(rec, 0u, k, d));
+                        a.dump_r[(size_t)frame * a.E + e0 + r * d + k] = __uint_as_float(ldsp_old_message(rec, zf, k, d));
                 }
             }
             if (r == 0) {
@@ -887,7 +1023,8 @@ struct LdspPlan {
     uint32_t *zf = nullptr;
     float *dump_p = nullptr, *dump_r = nullptr;
     int64_t dump_frames = 0;
-    bool flood = false;                 /* flood_ldsp_kernel (flooding min-sum) instead of the layered kernels */
+    int flood = 0;                      /* 0 layered kernels; flood_ldsp_kernel with 1: the MS chain's arithmetic (DecodeMS /
+                                           DecodeCPU), 2: the fused reference kernel's (DecodeMSCL) */
     int32_t grid = 0, block = 0, maxw = 0, per_cu = 0, wg_frames = 1;   /* wg_frames: frames per one-wave workgroup (z <= 32) */
     size_t lds_bytes = 0;
 };
@@ -907,11 +1044,15 @@ inline LdspKernel ldsp_kernel_for(int maxw) { return maxw <= 8 ? layered_ldsp_ke
  * only, last entry of that layer's rows, not an information column), lay the others out in LDS,
  * size the persistent grid and allocate its record rings.  eligible = false (and hipSuccess)
  * when the code does not fit this kernel. */
-inline LdspKernel flood_ldsp_kernel_for(int maxw) { return maxw <= 8 ? flood_ldsp_kernel<8> : flood_ldsp_kernel<16>; }
+inline LdspKernel flood_ldsp_kernel_for(int maxw, int kind)
+{
+    if (kind == 1) return maxw <= 8 ? flood_ldsp_kernel<8, true> : flood_ldsp_kernel<16, true>;
+    return maxw <= 8 ? flood_ldsp_kernel<8, false> : flood_ldsp_kernel<16, false>;
+}
 
 inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E, const std::vector<int32_t> &row_ptr,
                                    const std::vector<int32_t> &cols, int32_t z, int32_t K, int64_t max_batch, int device,
-                                   bool flood = false)
+                                   int flood = 0)
 {
     std::vector<int32_t> lp, bc, sh, e0;
     pl->eligible = false;
@@ -972,7 +1113,8 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
     hipError_t e;
     if ((e = up(&pl->hdr, hdr)) || (e = up(&pl->pack, pack)) || (e = up(&pl->col_slot, slot)) || (e = up(&pl->layer_e0, e0)))
         return e;
-    const void *k = flood ? (pl->wg_frames > 1 ? (const void *)flood_ldsp_packed_kernel : (const void *)flood_ldsp_kernel_for(mw <= 8 ? 8 : 16))
+    const void *k = flood ? (pl->wg_frames > 1 ? (flood == 1 ? (const void *)flood_ldsp_packed_kernel<true> : (const void *)flood_ldsp_packed_kernel<false>)
+                                               : (const void *)flood_ldsp_kernel_for(mw <= 8 ? 8 : 16, flood))
                     : pl->wg_frames > 1 ? (const void *)layered_ldsp_packed_kernel : (const void *)ldsp_kernel_for(mw <= 8 ? 8 : 16);
     /* the attribute belongs to the function, not to this plan: always the maximum, so that decoders
      * of different codes can coexist */
@@ -1011,8 +1153,9 @@ inline hipError_t ldsp_run(LdspPlan *pl, const FusedRun &r, hipStream_t s, int32
                r.max_iter, rounds, r.early_term};
     const unsigned grid = (unsigned)std::min<int64_t>((r.frames + pl->wg_frames - 1) / pl->wg_frames, pl->grid);
     if (!pl->eligible || grid == 0) return hipErrorInvalidValue;
-    if (pl->flood && pl->wg_frames > 1) flood_ldsp_packed_kernel<<<grid, 64, pl->lds_bytes, s>>>(a, pl->wg_frames);
-    else if (pl->flood) flood_ldsp_kernel_for(pl->maxw)<<<grid, pl->block, pl->lds_bytes, s>>>(a);
+    if (pl->flood == 1 && pl->wg_frames > 1) flood_ldsp_packed_kernel<true><<<grid, 64, pl->lds_bytes, s>>>(a, pl->wg_frames);
+    else if (pl->flood && pl->wg_frames > 1) flood_ldsp_packed_kernel<false><<<grid, 64, pl->lds_bytes, s>>>(a, pl->wg_frames);
+    else if (pl->flood) flood_ldsp_kernel_for(pl->maxw, pl->flood)<<<grid, pl->block, pl->lds_bytes, s>>>(a);
     else if (pl->wg_frames > 1) layered_ldsp_packed_kernel<<<grid, 64, pl->lds_bytes, s>>>(a, pl->wg_frames);
     else ldsp_kernel_for(pl->maxw)<<<grid, pl->block, pl->lds_bytes, s>>>(a);
     *launched = rounds;

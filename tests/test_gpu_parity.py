@@ -100,24 +100,28 @@ def test_layered_bit_exact_vs_fused_reference_kernel(built, path, V):
 
 
 @pytest.mark.parametrize("path", MSCL, ids=lambda p: p.split("mscl_")[-1][:-4])
-def test_fused_flooding_bit_exact_vs_reference_kernel(built, path):
+def test_fused_flooding_bit_exact_vs_reference_kernel(built, path, monkeypatch):
     """LDPC_ALGO_MS_FUSED (DecodeMSCL) against the reference's decodeOnceMS kernel outputs and
     the oracle's iteration counts / messages."""
     gd = load_golden(path)
     g, og, K, M, z = _graph(int(gd["rate"]), int(gd["N"]))
     y = gd["y"]
     B = y.shape[0]
-    dec = L.Decoder(g, K, max_batch=B, algo="ms_fused", max_iter=120, layer_rows=z)
-    out, iters = dec.decode(y)
-    assert np.array_equal(out, gd["out"])
     o = oracle.decode(og, y, "ms_fused", max_iter=120, tap_iter=2)
-    assert np.array_equal(iters, o["iters"])
-    dec.set_tap(2)
-    dec.decode(y)
-    run = np.nonzero(o["iters"] >= 2)[0]
-    assert np.array_equal(dec.dump(0, B)[run], o["taps"]["r"][run])
-    assert np.array_equal(dec.dump(2, B)[run], o["taps"]["post"][run])
-    dec.close()
+    # the record kernel (flood_ldsp_kernel, the default) and the LDS-resident fused_flood_kernel
+    for ldsp in ("1", "0"):
+        monkeypatch.setenv("LDPC_TUNE_LDSP", ldsp)
+        monkeypatch.setenv("LDPC_TUNE_LDSP_GRID", "3")
+        dec = L.Decoder(g, K, max_batch=B, algo="ms_fused", max_iter=120, layer_rows=z)
+        out, iters = dec.decode(y)
+        assert np.array_equal(out, gd["out"]), ldsp
+        assert np.array_equal(iters, o["iters"]), ldsp
+        dec.set_tap(2)
+        dec.decode(y)
+        run = np.nonzero(o["iters"] >= 2)[0]
+        assert np.array_equal(dec.dump(0, B)[run], o["taps"]["r"][run]), ldsp
+        assert np.array_equal(dec.dump(2, B)[run], o["taps"]["post"][run]), ldsp
+        dec.close()
 
 
 def test_layered_streaming_and_fused_paths_agree(built, monkeypatch):
@@ -255,7 +259,7 @@ def test_degenerate_channel_values(built, algo, monkeypatch):
     y[9, :] = -1.0
     y[10, rng.choice(N, 300, replace=False)] *= 400.0             # magnitudes beyond the 1000 clip
     y[11, ::2] = 0.0
-    for fused in (("1",) if algo == "ms_fused" else (("1", "ldsp", "0") if algo in ("layered", "ms") else ("1", "0"))):
+    for fused in (("1", "ldsp") if algo == "ms_fused" else (("1", "ldsp", "0") if algo in ("layered", "ms") else ("1", "0"))):
         monkeypatch.setenv("LDPC_TUNE_FUSED", "1" if fused == "ldsp" else fused)
         monkeypatch.setenv("LDPC_TUNE_LDSP", "1" if fused == "ldsp" else "0")
         dec = L.Decoder(g, K, max_batch=24, algo=algo, max_iter=15, layer_rows=z)

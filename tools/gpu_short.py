@@ -15,7 +15,7 @@ torch.manual_seed(1)
 y = 1.0 + sigma * torch.randn(B, N, device="cuda")
 out = torch.empty(L.out_bytes(K, B), dtype=torch.uint8, device="cuda")
 it = torch.empty(B, dtype=torch.int32, device="cuda")
-for fused in ("1", "ldsp", "0") if algo in ("layered", "ms") else ("1", "0"):
+for fused in ("1", "ldsp", "0") if algo in ("layered", "ms") else (("1", "ldsp") if algo == "ms_fused" else ("1", "0")):
     os.environ["LDPC_TUNE_FUSED"] = "1" if fused == "ldsp" else fused
     os.environ["LDPC_TUNE_LDSP"] = "1" if fused == "ldsp" else "0"
     dec = L.Decoder(g, K, max_batch=B, algo=algo, layer_rows=z, max_iter=40, poll_interval=0)
