@@ -263,6 +263,7 @@ int Coder::decode(float *postCode, char *srcCode, int srcLength, enum decodeType
             ldpc_decoder_config_init(&cfg);
             cfg.K = ldpcK; cfg.max_batch = codeSize; cfg.max_iter = times; cfg.device = device;
             cfg.algo = LDPC_ALGO_MS; cfg.pack_mode = LDPC_PACK_BITS; cfg.early_term = 1; cfg.poll_interval = 4;
+            cfg.layer_rows = z;                              /* circulant size: lets the one-launch kernels apply */
             int rc = ldpc_decoder_create(graph, &cfg, &d);
             if (rc) return fail(rc, ldpc_last_error());
             decoders[(int)DecodeCPU] = d;
