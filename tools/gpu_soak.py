@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Randomized soak of the quasi-cyclic decoders against the CPU oracle (test infrastructure:
+imports oracle/).  Random base matrices (circulant size, layers, row weights 1..24, single-layer
+columns anywhere), random noise levels, a few zeros / huge values / NaNs in the channel values;
+layered, min-sum and fused-flooding min-sum, each on the record kernels (default), on the
+LDS-resident kernels and on the streaming kernels.  usage: gpu_soak.py [cases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import myldpccppapi_amd as L
+from myldpccppapi_amd import codes, channel
+import oracle
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for case in range(cases):
+    z = int(rng.choice([3, 7, 16, 24, 27, 31, 32, 33, 48, 63, 64, 65, 96, 100, 128, 130, 200]))
+    mb = int(rng.integers(1, 13))
+    nb = int(rng.integers(mb + 1, mb + 30))
+    dmax = int(rng.integers(1, min(24, nb) + 1))
+    base = -np.ones((mb, nb), np.int64)
+    for i in range(mb):
+        d = int(rng.integers(1, dmax + 1))
+        base[i, rng.choice(nb, d, replace=False)] = rng.integers(0, z, d)
+    for j in range(nb):
+        if (base[:, j] < 0).all():
+            i = int(rng.integers(0, mb))
+            if (base[i] >= 0).sum() < 24:
+                base[i, j] = rng.integers(0, z)
+    base = base[:, [j for j in range(nb) if (base[:, j] >= 0).any()]]
+    mb, nb = base.shape
+    M, N = mb * z, nb * z
+    K = max(8, min(N, (nb - min(mb, nb - 1)) * z - int(rng.integers(0, z))) // 8 * 8)
+    rows, cols = codes.qc_edges(base, z)
+    g = L.Graph(rows, cols, M, N)
+    og = oracle.Graph(rows, cols, M, N, K)
+    B = int(rng.integers(1, 40))
+    y = channel.awgn_frames(N, 0, B, float(rng.uniform(0.3, 1.2)), seed=1000 + case)
+    if B > 2:
+        y[1, rng.choice(N, max(1, N // 7), replace=False)] = 0.0
+        y[2, rng.choice(N, max(1, N // 50), replace=False)] *= 3000.0
+    if B > 4 and rng.random() < 0.3:
+        y[4, rng.choice(N, 2, replace=False)] = np.nan
+    iters = int(rng.integers(1, 25))
+    for algo in ("layered", "ms", "ms_fused"):
+        want = oracle.decode(og, y, algo, layer_rows=z, max_iter=iters)
+        ok = want["undefined"] == 0 if "undefined" in want else np.ones(B, bool)
+        kb = K // 8
+        for mode, env in (("record", {"LDPC_TUNE_FUSED": "1", "LDPC_TUNE_LDSP": "1"}),
+                          ("lds", {"LDPC_TUNE_FUSED": "1", "LDPC_TUNE_LDSP": "0"}),
+                          ("stream", {"LDPC_TUNE_FUSED": "0", "LDPC_TUNE_LDSP": "0"})):
+            if algo == "ms_fused" and mode == "stream":
+                continue
+            os.environ.update(env)
+            os.environ["LDPC_TUNE_LDSP_GRID"] = str(int(rng.integers(1, 9)))
+            try:
+                dec = L.Decoder(g, K, max_batch=B, algo=algo, layer_rows=z, max_iter=iters)
+            except L.LdpcError as e:
+                if algo == "ms_fused":
+                    continue            # not every structure fits the one-launch kernels
+                raise
+            out, it = dec.decode(y)
+            good = np.array_equal(out.reshape(B, kb)[ok], want["out"].reshape(B, kb)[ok]) and np.array_equal(it[ok], want["iters"][ok])
+            dec.close()
+            if not good:
+                bad += 1
+                print("MISMATCH case", case, "z", z, "base", base.shape, "K", K, "B", B, "iters", iters, algo, mode, flush=True)
+    print("case %d ok: z=%d base=%dx%d K=%d B=%d iters=%d" % (case, z, mb, nb, K, B, iters), flush=True)
+print("soak finished:", cases, "cases,", bad, "mismatches")
+sys.exit(1 if bad else 0)
