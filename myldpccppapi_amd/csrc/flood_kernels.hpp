@@ -46,6 +46,7 @@ namespace ldpc {
 
 constexpr int kAlgoSP = 0;
 constexpr int kAlgoMS = 1;
+constexpr int kCompactCapacity = 256;   /* frames a child decoder takes over (4 tiles of 64) */
 constexpr int kBlock = 256;          /* 4 waves */
 constexpr int kWavesPerBlock = 4;
 constexpr int kMaxUnrolledDegree = 16;       /* variable-node kernels, sum-product check kernels */
@@ -978,7 +979,7 @@ struct StateArgs {
     uint64_t *__restrict__ done;        /* [T][V] */
     const uint64_t *__restrict__ fail;  /* [T][V] syndrome of round `iter` */
     int32_t *__restrict__ iters;        /* [T][F] */
-    int32_t *__restrict__ active;       /* [1] set to 1 if any frame is still running */
+    int32_t *__restrict__ active;       /* [1] += number of frames still running */
     int64_t frames;
     int32_t iter;                       /* round whose syndrome `fail` holds; 0 = initialise */
     int32_t max_iter;
@@ -993,7 +994,7 @@ template <int V> __global__ void state_kernel(const StateArgs a)
     constexpr int F = 64 * V;
     const int tile = blockIdx.x;
     const int lane = threadIdx.x;      /* 64 threads */
-    bool any_active = false;
+    int n_active = 0;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         const int64_t frame = (int64_t)tile * F + (int64_t)lane * V + v;
@@ -1010,9 +1011,94 @@ template <int V> __global__ void state_kernel(const StateArgs a)
             d = a.freeze ? (old | clean) : old;
         }
         if (lane == 0) a.done[(size_t)tile * V + v] = d;
-        any_active = any_active || (d != ~0ull);
+        n_active += __popcll(~d);
     }
-    if (lane == 0 && any_active && a.active) atomicOr(a.active, 1);
+    if (lane == 0 && n_active && a.active) atomicAdd(a.active, n_active);
+}
+
+/* ---- tail compaction (early termination): when only a few frames of a large batch are still
+ * running, their state moves into ONE 64-frame tile of a small child decoder, which finishes
+ * them; the parent's tiles stop being launched.  Frames are independent, so nothing changes for
+ * any frame except where its state lives.
+ * compact_list_kernel: map[slot] = frame index of every running frame (slot order is arbitrary). */
+template <int V> __global__ __launch_bounds__(kBlock) void compact_list_kernel(const uint64_t *__restrict__ done, int64_t frames,
+                                                                               int32_t *__restrict__ map, int32_t *__restrict__ count,
+                                                                               int32_t capacity)
+{
+    constexpr int F = 64 * V;
+    const int64_t f = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (f >= frames) return;
+    const int64_t tile = f / F;
+    const int fi = (int)(f % F);
+    if ((done[tile * V + fi % V] >> (fi / V)) & 1ull) return;
+    const int slot = atomicAdd(count, 1);
+    if (slot < capacity) map[slot] = (int32_t)f;
+}
+
+/* dst[i][j] = src[tile(map[j])][i][position of map[j]] for j < count (0 beyond): the per-edge /
+ * per-column values of the running frames, gathered into a V = 1 tile.  One wave per row i. */
+template <int V, typename T>
+__global__ __launch_bounds__(kBlock) void compact_gather_kernel(const T *__restrict__ src, T *__restrict__ dst,
+                                                                const int32_t *__restrict__ map, int32_t count, int64_t rows)
+{
+    constexpr int F = 64 * V;
+    const int j = threadIdx.x & 63, ct = blockIdx.y, jg = ct * 64 + j;      /* child tile ct, slot jg */
+    const int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + wave_id_in_block();
+    if (i >= rows) return;
+    T val = (T)0;
+    if (jg < count) {
+        const int64_t f = map[jg];
+        val = src[((f / F) * rows + i) * F + (f % F)];
+    }
+    dst[((size_t)ct * rows + i) * 64 + j] = val;
+}
+
+/* hard bits: child word n = bit j <- parent bit of frame map[j] (gather), and back (scatter; also the
+ * iteration counts and the converged flags) */
+template <int V> __global__ __launch_bounds__(kBlock) void compact_hard_kernel(uint64_t *__restrict__ parent, uint64_t *__restrict__ child,
+                                                                               const int32_t *__restrict__ map, int32_t count, int32_t N,
+                                                                               int scatter)
+{
+    constexpr int F = 64 * V;
+    const int j = threadIdx.x & 63, ct = blockIdx.y, jg = ct * 64 + j;
+    const int64_t n = (int64_t)blockIdx.x * kWavesPerBlock + wave_id_in_block();
+    if (n >= N) return;
+    const int64_t f = jg < count ? map[jg] : 0;
+    const int fi = (int)(f % F);
+    unsigned long long *word = reinterpret_cast<unsigned long long *>(parent) + ((f / F) * N + n) * V + fi % V;
+    uint64_t *cw = child + (size_t)ct * N + n;                             /* child: V = 1, hard[tile][n] */
+    const int l = fi / V;
+    if (!scatter) {
+        const bool bit = jg < count && ((*word >> l) & 1ull);
+        const uint64_t w = __ballot(bit);
+        if (j == 0) *cw = w;
+    } else if (jg < count) {
+        if ((*cw >> j) & 1ull) atomicOr(word, 1ull << l);
+        else atomicAnd(word, ~(1ull << l));
+    }
+}
+
+template <int V> __global__ void compact_finish_kernel(uint64_t *__restrict__ parent_done, int32_t *__restrict__ parent_iters,
+                                                       const uint64_t *__restrict__ child_done, const int32_t *__restrict__ child_iters,
+                                                       const int32_t *__restrict__ map, int32_t count)
+{
+    constexpr int F = 64 * V;
+    const int j = threadIdx.x, ct = blockIdx.x, jg = ct * 64 + j;          /* 64 threads per child tile */
+    if (jg >= count) return;
+    const int64_t f = map[jg];
+    const int fi = (int)(f % F);
+    parent_iters[f] = child_iters[jg];
+    if ((child_done[ct] >> j) & 1ull)
+        atomicOr(reinterpret_cast<unsigned long long *>(parent_done) + (f / F) * V + fi % V, 1ull << (fi / V));
+}
+
+/* the child's bookkeeping when it takes over `count` running frames: lanes beyond are padding */
+__global__ void compact_child_state_kernel(uint64_t *__restrict__ done, int32_t *__restrict__ iters, int32_t count, int32_t max_iter)
+{
+    const int j = threadIdx.x, ct = blockIdx.x, jg = ct * 64 + j;          /* 64 threads per child tile */
+    iters[jg] = max_iter;
+    const uint64_t pad = __ballot(jg >= count);
+    if (j == 0) done[ct] = pad;
 }
 
 struct PackArgs {

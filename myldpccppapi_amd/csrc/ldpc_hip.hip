@@ -223,6 +223,12 @@ struct ldpc_decoder {
     } slot[2];
     bool suppress_poll = false;
     int32_t *h_active = nullptr;        /* pinned */
+    /* tail compaction (flood_kernels.hpp): a V = 1, one-tile decoder that takes over the last running
+     * frames of a polled, early-terminating decode */
+    ldpc_decoder *child = nullptr;
+    DevBuf<int32_t> cmap;               /* [kCompactCapacity] frame indices handed to the child */
+    int compact_threshold = ldpc::kCompactCapacity;   /* LDPC_TUNE_COMPACT: 0 = off, else hand over when <= this many frames run */
+    bool is_child = false;
 
     bool timing = false;                /* the call being enqueued is timed */
     int timing_every = 0;               /* 0 off, k: every k-th device call is timed */
@@ -254,6 +260,7 @@ struct ldpc_decoder {
         }
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (stream) (void)hipStreamDestroy(stream);
+        delete child;
     }
 };
 
@@ -315,7 +322,43 @@ hipError_t span_end(ldpc_decoder *d, hipStream_t s)
 
 template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t frames,
                                   uint8_t *out_dev, int64_t out_bytes, int32_t *iters_dev,
-                                  hipStream_t s)
+                                  hipStream_t s, int start_round = 1);
+
+/* Hand the `count` frames that are still running after round `it` over to the child decoder, let it
+ * finish them (rounds it+1 ...), and bring their bits, iteration counts and converged flags back. */
+template <int V> int compact_and_finish(ldpc_decoder *d, int64_t frames, int count, int it, hipStream_t s)
+{
+    using namespace ldpc;
+    ldpc_decoder *c = d->child;
+    const unsigned ct = (unsigned)((count + 63) / 64);      /* child tiles in use */
+    HIP_TRY(hipMemsetAsync(d->active.p, 0, sizeof(int32_t), s));
+    compact_list_kernel<V><<<(unsigned)((frames + kBlock - 1) / kBlock), kBlock, 0, s>>>(d->done.p, frames, d->cmap.p,
+                                                                                         d->active.p, kCompactCapacity);
+    const dim3 ge((unsigned)((d->E + kWavesPerBlock - 1) / kWavesPerBlock), ct);
+    const dim3 gn((unsigned)((d->N + kWavesPerBlock - 1) / kWavesPerBlock), ct);
+    if (d->msg_size == 2) {
+        compact_gather_kernel<V, _Float16><<<ge, kBlock, 0, s>>>((const _Float16 *)d->Q.p, (_Float16 *)c->Q.p, d->cmap.p, count, d->E);
+        compact_gather_kernel<V, _Float16><<<gn, kBlock, 0, s>>>((const _Float16 *)d->chan.p, (_Float16 *)c->chan.p, d->cmap.p, count, d->N);
+    } else {
+        compact_gather_kernel<V, float><<<ge, kBlock, 0, s>>>((const float *)d->Q.p, (float *)c->Q.p, d->cmap.p, count, d->E);
+        compact_gather_kernel<V, float><<<gn, kBlock, 0, s>>>((const float *)d->chan.p, (float *)c->chan.p, d->cmap.p, count, d->N);
+    }
+    compact_hard_kernel<V><<<gn, kBlock, 0, s>>>(d->hard.p, c->hard.p, d->cmap.p, count, d->N, 0);
+    compact_child_state_kernel<<<ct, 64, 0, s>>>(c->done.p, c->iters.p, count, d->cfg.max_iter);
+    HIP_TRY(hipGetLastError());
+    c->timing = false;
+    c->tap_iter = 0;
+    const int rc = run_flooding<1>(c, nullptr, count, nullptr, 0, nullptr, s, it + 1);
+    if (rc) return rc;
+    compact_hard_kernel<V><<<gn, kBlock, 0, s>>>(d->hard.p, c->hard.p, d->cmap.p, count, d->N, 1);
+    compact_finish_kernel<V><<<ct, 64, 0, s>>>(d->done.p, d->iters.p, c->done.p, c->iters.p, d->cmap.p, count);
+    HIP_TRY(hipGetLastError());
+    return LDPC_OK;
+}
+
+template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t frames,
+                                  uint8_t *out_dev, int64_t out_bytes, int32_t *iters_dev,
+                                  hipStream_t s, int start_round)
 {
     using namespace ldpc;
     const int F = 64 * V;
@@ -326,22 +369,23 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
     const bool freeze = d->cfg.early_term != 0;
     const size_t slot = (size_t)d->T * V;   /* words per fail slot */
 
+    const bool resume = start_round > 1;    /* a child taking over running frames: their state is in place */
     HIP_TRY(hipMemsetAsync(d->failw.p, 0, d->failw.n * sizeof(uint64_t), s));
     HIP_TRY(hipMemsetAsync(d->summary.p, 0, 2 * sizeof(int32_t), s));
 
-    HIP_TRY(span_begin(d, s, 3));
-    {
+    if (!resume) {
+        HIP_TRY(span_begin(d, s, 3));
         InitArgs a{llr_dev, d->chan.p, d->Q.p, d->hard.p, d->col_ptr.p, d->col_edge.p,
                    d->E, frames, d->N, d->cfg.llr_scale};
         dim3 grid((d->N + kInitCols - 1) / kInitCols, tiles);
         d->init_fn<<<grid, kBlock, 0, s>>>(a);
         StateArgs st{d->done.p, nullptr, d->iters.p, nullptr, frames, 0, max_iter, freeze ? 1 : 0};
         state_kernel<V><<<tiles, 64, 0, s>>>(st);
+        HIP_TRY(span_end(d, s));
     }
-    HIP_TRY(span_end(d, s));
 
-    int launched = 0;
-    for (int it = 1; it <= rounds; ++it) {
+    int launched = start_round - 1;
+    for (int it = start_round; it <= rounds; ++it) {
         /* check_i: R_i = check(Q_{i-1}) */
         for (auto &rc : d->row_classes) {
             /* algorithmic bytes: the fused columns' messages and channel values count as in the
@@ -406,11 +450,19 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
                 HIP_TRY(hipMemcpyAsync(d->h_active, d->active.p, sizeof(int32_t),
                                        hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
-                if (*d->h_active == 0) break;   /* every frame frozen: MyLdpc.cpp:1035-1036 */
+                const int running = *d->h_active;
+                if (running == 0) break;        /* every frame frozen: MyLdpc.cpp:1035-1036 */
+                if (d->child && running <= d->compact_threshold && (int64_t)running * 4 <= frames && tiles > 1 && !d->tap_iter) {
+                    const int rc = compact_and_finish<V>(d, frames, running, it, s);
+                    if (rc) return rc;
+                    launched = d->child->last_iterations;
+                    break;
+                }
             }
         }
     }
     d->last_iterations = launched;
+    if (resume) return LDPC_OK;             /* the parent packs */
 
     HIP_TRY(span_begin(d, s, 3));
     {
@@ -540,6 +592,9 @@ int setup_flooding(ldpc_decoder *d, const ldpc_graph *g, size_t TF)
 }  // namespace
 
 /* ================================================================== C ABI */
+
+/* set while a decoder creates its tail-compaction child: the child must not create one of its own */
+static thread_local bool t_creating_child = false;
 
 extern "C" {
 
@@ -786,6 +841,22 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
         if (!d->use_fused) {
             int rc = setup_flooding(d, g, TF);
             if (rc) return rc;
+            /* tail compaction: with host polling on, the last <= 256 running frames of a batch of several
+             * tiles are finished by a small (4 x 64 frames) child decoder (LDPC_TUNE_COMPACT=0: off, n: threshold) */
+            if (const char *e = getenv("LDPC_TUNE_COMPACT")) d->compact_threshold = std::min(ldpc::kCompactCapacity, std::max(0, atoi(e)));
+            if (cfg->early_term && cfg->poll_interval > 0 && d->T > 1 && d->compact_threshold > 0 && !t_creating_child) {
+                ldpc_decoder_config cc = *cfg;
+                cc.max_batch = ldpc::kCompactCapacity;
+                cc.frames_per_lane = 1;
+                cc.layer_rows = 0;                 /* streaming kernels, same arithmetic */
+                t_creating_child = true;
+                rc = ldpc_decoder_create(g, &cc, &d->child);
+                t_creating_child = false;
+                if (rc) return rc;
+                d->child->is_child = true;
+                HIP_TRY(hipSetDevice(cfg->device));
+                HIP_TRY(d->cmap.alloc(ldpc::kCompactCapacity));
+            }
         }
     }
     *out = guard.release();

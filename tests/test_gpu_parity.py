@@ -605,3 +605,32 @@ def test_layered_on_random_quasi_cyclic_codes(built, monkeypatch):
             out, iters = dec.decode(y)
             assert np.array_equal(out, want_ms["out"]) and np.array_equal(iters, want_ms["iters"]), (z, base.shape, K, mode, "ms")
             dec.close()
+
+
+@pytest.mark.parametrize("algo,f16", [("sp", False), ("ms", False), ("ms", True)])
+def test_tail_compaction_of_running_frames(built, algo, f16, monkeypatch):
+    """Early termination with host polling: once at most `threshold` frames of a multi-tile batch are
+    still running, their state moves into a one-tile child decoder that finishes them.  Bits,
+    iteration counts and the converged count must be those of the oracle (frames are independent);
+    with compaction off the same."""
+    g, og, K, M, z = _graph(codes.RATE_1_2, 1152)
+    B = 700
+    rng = np.random.default_rng(40)
+    y = channel.awgn_frames(1152, 0, B, 0.62, seed=41)            # most frames converge within a few rounds ...
+    hard = rng.choice(B, 90, replace=False)
+    y[hard] = channel.awgn_frames(1152, 5000, 90, 1.05, seed=42)  # ... some scattered ones (almost) never do: two child tiles
+    want = oracle.decode(og, y, algo, max_iter=30, msg_f16=f16)
+    assert (want["iters"] == 30).sum() >= 65 and (want["iters"] < 12).sum() > B - 120
+    for compact in ("256", "7", "0"):
+        monkeypatch.setenv("LDPC_TUNE_COMPACT", compact)
+        for fpl in (1, 2, 4):
+            dec = L.Decoder(g, K, max_batch=B, algo=algo, max_iter=30, poll_interval=1, frames_per_lane=fpl,
+                            msg_dtype="f16" if f16 else "f32")
+            for _ in range(2):                                    # the child is reused by the second call
+                out, iters = dec.decode(y)
+                assert np.array_equal(out, want["out"]), (compact, fpl)
+                assert np.array_equal(iters, want["iters"]), (compact, fpl)
+                st = dec.stats()
+                assert st["frames_converged"] == int((want["iters"] < 30).sum()) or (want["iters"] == 30).any()
+                assert st["iterations_launched"] == 30
+            dec.close()
