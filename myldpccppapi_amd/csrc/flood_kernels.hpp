@@ -46,7 +46,7 @@ namespace ldpc {
 
 constexpr int kAlgoSP = 0;
 constexpr int kAlgoMS = 1;
-constexpr int kCompactCapacity = 256;   /* frames a child decoder takes over (4 tiles of 64) */
+constexpr int kCompactCapacity = 512;   /* frames a child decoder takes over (8 tiles of 64) */
 constexpr int kBlock = 256;          /* 4 waves */
 constexpr int kWavesPerBlock = 4;
 constexpr int kMaxUnrolledDegree = 16;       /* variable-node kernels, sum-product check kernels */

@@ -841,8 +841,8 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
         if (!d->use_fused) {
             int rc = setup_flooding(d, g, TF);
             if (rc) return rc;
-            /* tail compaction: with host polling on, the last <= 256 running frames of a batch of several
-             * tiles are finished by a small (4 x 64 frames) child decoder (LDPC_TUNE_COMPACT=0: off, n: threshold) */
+            /* tail compaction: with host polling on, the last <= 512 running frames of a batch of several
+             * tiles are finished by a small (8 x 64 frames) child decoder (LDPC_TUNE_COMPACT=0: off, n: threshold) */
             if (const char *e = getenv("LDPC_TUNE_COMPACT")) d->compact_threshold = std::min(ldpc::kCompactCapacity, std::max(0, atoi(e)));
             if (cfg->early_term && cfg->poll_interval > 0 && d->T > 1 && d->compact_threshold > 0 && !t_creating_child) {
                 ldpc_decoder_config cc = *cfg;

@@ -621,7 +621,7 @@ def test_tail_compaction_of_running_frames(built, algo, f16, monkeypatch):
     y[hard] = channel.awgn_frames(1152, 5000, 90, 1.05, seed=42)  # ... some scattered ones (almost) never do: two child tiles
     want = oracle.decode(og, y, algo, max_iter=30, msg_f16=f16)
     assert (want["iters"] == 30).sum() >= 65 and (want["iters"] < 12).sum() > B - 120
-    for compact in ("256", "7", "0"):
+    for compact in ("512", "7", "0"):
         monkeypatch.setenv("LDPC_TUNE_COMPACT", compact)
         for fpl in (1, 2, 4):
             dec = L.Decoder(g, K, max_batch=B, algo=algo, max_iter=30, poll_interval=1, frames_per_lane=fpl,
