@@ -22,6 +22,9 @@
  *     step ahead.  Workgroups are persistent and walk over the frames, so the record rings
  *     (M * 16 B per resident workgroup) stay in L2 / Infinity Cache: HBM sees the channel values
  *     once and the packed bits once.
+ * Kernels in this file: layered_ldsp_kernel (+ _packed_: 64/z frames per wave for z <= 32) -- layered
+ * min-sum; flood_ldsp_kernel<.., CHAIN> (+ _packed_) -- flooding min-sum with the MS kernel chain's
+ * arithmetic (DecodeMS / DecodeCPU) or the fused reference kernel's (DecodeMSCL), two posterior images.
  * Arithmetic: the operations of layer_kernel / the oracle in the same order; where every q of a
  * wave's rows is a regular number (not zero, not NaN, product not underflowed) the sign algebra
  * is done on the bit patterns -- identical results, a third of the instructions; otherwise the
