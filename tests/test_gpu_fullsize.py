@@ -200,3 +200,30 @@ def test_full_batch_4096_frames_indexing(built, code):
     assert (iters == 12).all() and dec.stats()["frames_converged"] == 0
     dec.close()
     del y
+
+
+def test_tail_compaction_at_full_size(built, code):
+    """configs[1] dimensions, min-sum with early termination and host polling: 4096 frames of which
+    all but 37 converge within a few rounds; the stragglers (spread over all 16 tiles, element
+    offsets beyond 2^31 in the gather) are finished by the child decoder.  Every frame's iteration
+    count against the oracle's for a sample, the stragglers' bits and counts against the oracle."""
+    rows, cols, g, og = code
+    B = 4096
+    rng = np.random.default_rng(78)
+    y = (1.0 + 0.72 * rng.standard_normal((B, N), dtype=np.float32)).astype(np.float32)
+    slow = np.sort(rng.choice(B, 37, replace=False))
+    y[slow] = (1.0 + 0.86 * rng.standard_normal((37, N), dtype=np.float32)).astype(np.float32)
+    dec = L.Decoder(g, K, max_batch=B, algo="ms", max_iter=25, poll_interval=1)
+    out, iters = dec.decode(y)
+    st = dec.stats()
+    pick = np.r_[slow[[0, 5, 18, 36]], [0, 255, 2048, 4095]]
+    o = oracle.decode(og, y[pick], "ms", max_iter=25)
+    kb = K // 8
+    for i, f in enumerate(pick):
+        assert np.array_equal(out[f * kb:(f + 1) * kb], o["out"][i * kb:(i + 1) * kb]), f
+        assert iters[f] == o["iters"][i], f
+    fast = np.setdiff1d(np.arange(B), slow)
+    assert iters[fast].max() < 25 and iters[slow].min() > iters[fast].max()        # the premise of the test
+    assert st["frames_converged"] == int((iters < 25).sum())
+    assert st["iterations_launched"] == int(iters.max())
+    dec.close()
