@@ -67,5 +67,35 @@ for case in range(cases):
                 bad += 1
                 print("MISMATCH case", case, "z", z, "base", base.shape, "K", K, "B", B, "iters", iters, algo, mode, flush=True)
     print("case %d ok: z=%d base=%dx%d K=%d B=%d iters=%d" % (case, z, mb, nb, K, B, iters), flush=True)
+# second phase: streaming kernels with early termination, host polling and tail compaction on 802.16e
+# codes: mixed noise levels so that a few stragglers remain while most frames have converged
+for case in range(max(4, cases // 6)):
+    rate = int(rng.integers(0, 6))
+    N = int(rng.choice([576, 672, 960, 1152, 2304]))
+    K, M, z = codes.wimax_dims(rate, N)
+    rows, cols = codes.wimax_edges(rate, N)
+    g = L.Graph(rows, cols, M, N)
+    og = oracle.Graph(rows, cols, M, N, K)
+    B = int(rng.integers(130, 900))
+    y = channel.awgn_frames(N, 0, B, float(rng.uniform(0.3, 0.6)) * (1.0 if rate < 3 else 0.7), seed=5000 + case)
+    ns = int(rng.integers(1, 60))
+    slow = rng.choice(B, ns, replace=False)
+    y[slow] = channel.awgn_frames(N, 7000, ns, float(rng.uniform(0.9, 1.4)), seed=6000 + case)
+    algo = ("sp", "ms", "ms")[case % 3]
+    f16 = algo == "ms" and case % 2 == 1
+    iters = int(rng.integers(5, 30))
+    want = oracle.decode(og, y, algo, max_iter=iters, msg_f16=f16)
+    os.environ["LDPC_TUNE_FUSED"] = "0"
+    os.environ["LDPC_TUNE_LDSP"] = "0"
+    os.environ["LDPC_TUNE_COMPACT"] = str(int(rng.choice([512, 512, 64, 9])))
+    dec = L.Decoder(g, K, max_batch=B, algo=algo, max_iter=iters, poll_interval=int(rng.integers(1, 4)),
+                    frames_per_lane=int(rng.choice([1, 2, 4])), msg_dtype="f16" if f16 else "f32")
+    out, it = dec.decode(y)
+    good = np.array_equal(out, want["out"]) and np.array_equal(it, want["iters"])
+    dec.close()
+    if not good:
+        bad += 1
+        print("MISMATCH streaming case", case, rate, N, B, algo, f16, iters, flush=True)
+    print("streaming case %d ok: rate=%d N=%d B=%d %s%s iters=%d stragglers=%d" % (case, rate, N, B, algo, "16" if f16 else "", iters, ns), flush=True)
 print("soak finished:", cases, "cases,", bad, "mismatches")
 sys.exit(1 if bad else 0)
