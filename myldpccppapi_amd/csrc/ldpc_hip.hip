@@ -208,8 +208,8 @@ struct ldpc_decoder {
     ldpc::LdspPlan ldsp;                /* LDPC_ALGO_LAYERED, mid-size QC codes: posterior in LDS, check records in cache */
     bool use_ldsp = false;
 
-    /* staging for the host-buffer entry point: two slots, so the H2D copy of group k+1
-     * (copy_stream) overlaps the decode of group k (stream) */
+    /* staging for the host-buffer entry point: three slots, so the H2D copy of group k+1
+     * (copy_stream) overlaps the decode of group k (stream) and the copy-out of group k-1 */
     hipStream_t stream = nullptr, copy_stream = nullptr;
     struct HostSlot {
         DevBuf<float> llr;
@@ -220,7 +220,7 @@ struct ldpc_decoder {
         hipEvent_t h2d_done = nullptr, all_done = nullptr;
         bool busy = false;
         int64_t off = 0, n = 0, dst = 0, copy_bytes = 0;
-    } slot[2];
+    } slot[3];
     bool suppress_poll = false;
     int32_t *h_active = nullptr;        /* pinned */
     /* tail compaction (flood_kernels.hpp): a V = 1, one-tile decoder that takes over the last running
@@ -947,7 +947,11 @@ int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
         return fail(LDPC_ERR_UNSUPPORTED, "bit-packed output with K %% 8 != 0 cannot be chunked: "
                     "raise max_batch to cover all %lld frames", (long long)frames);
     const int64_t stage_out = ldpc_out_bytes(d->cfg.K, B, d->cfg.pack_mode) + 8;
-    const int nslots = frames > B ? 2 : 1;
+    /* more than one group: three staging slots, so that group k+1's channel values are copied in while
+     * group k is decoded (the host may block in group k's early-termination polls) and group k-1's
+     * results are copied out */
+    const int nslots = frames > B ? 3 : 1;
+    const int64_t ngroups = (frames + B - 1) / B;
     if (!d->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < nslots; ++i) {
         auto &sl = d->slot[i];
@@ -970,25 +974,23 @@ int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
         sl.busy = false;
         return LDPC_OK;
     };
-    /* Coder::decode, MyLdpc.cpp:577-616: groups of batchSize frames, last one short.  With more
-     * than one group the host does not poll for early exit (finished tiles still skip on the
-     * device): polling would block the host exactly when it should be copying the next group. */
-    d->suppress_poll = nslots > 1;
     std::vector<void *> pinned;
     int rc = LDPC_OK;
-    int k = 0;
     const bool trace = getenv("LDPC_TRACE_HOST") != nullptr;
     const auto t_start = std::chrono::steady_clock::now();
-    auto stamp = [&](const char *what, int kk) {
+    auto stamp = [&](const char *what, int64_t kk) {
         if (trace)
-            fprintf(stderr, "[ldpc_decode] %8.2f ms  group %d  %s\n",
-                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), kk, what);
+            fprintf(stderr, "[ldpc_decode] %8.2f ms  group %lld  %s\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(),
+                    (long long)kk, what);
     };
-    for (int64_t off = 0; off < frames && rc == LDPC_OK; off += B, ++k) {
-        auto &sl = d->slot[k % nslots];
-        if ((rc = drain(sl))) break;
-        stamp("slot free", k);
-        const int64_t n = std::min(B, frames - off);
+    /* Coder::decode, MyLdpc.cpp:577-616: groups of batchSize frames, last one short.
+     * stage_in(k): group k's channel values -> slot k % nslots, on the copy stream. */
+    auto stage_in = [&](int64_t kk) -> int {
+        auto &sl = d->slot[kk % nslots];
+        const int r1 = drain(sl);                /* the slot's previous tenant (group kk - nslots) */
+        if (r1) return r1;
+        const int64_t off = kk * B, n = std::min(B, frames - off);
         /* A copy from pageable memory waits for the device's other work (measured: 151 ms behind
          * a 140 ms decode instead of 19 ms); pinning the caller's pages for the duration of the
          * copy makes it a true DMA that runs beside the previous group's kernels. */
@@ -997,12 +999,18 @@ int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
             pinned.push_back((void *)src);      /* unpinned after the last group: unregistering waits for the device */
         else
             (void)hipGetLastError();
-        stamp("pinned", k);
-        hipError_t e = hipMemcpyAsync(sl.llr.p, src, (size_t)n * d->N * sizeof(float),
-                                      hipMemcpyHostToDevice, d->copy_stream);
-        stamp("H2D returned", k);
+        hipError_t e = hipMemcpyAsync(sl.llr.p, src, (size_t)n * d->N * sizeof(float), hipMemcpyHostToDevice, d->copy_stream);
         if (e == hipSuccess) e = hipEventRecord(sl.h2d_done, d->copy_stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(d->stream, sl.h2d_done, 0);
+        if (e != hipSuccess) return fail(LDPC_ERR_HIP, "host-to-device staging: %s", hipGetErrorString(e));
+        stamp("H2D enqueued", kk);
+        return LDPC_OK;
+    };
+    rc = stage_in(0);
+    for (int64_t k = 0; k < ngroups && rc == LDPC_OK; ++k) {
+        auto &sl = d->slot[k % nslots];
+        const int64_t off = k * B, n = std::min(B, frames - off);
+        if (k + 1 < ngroups && (rc = stage_in(k + 1))) break;   /* runs beside this group's decode */
+        hipError_t e = hipStreamWaitEvent(d->stream, sl.h2d_done, 0);
         if (e != hipSuccess) { rc = fail(LDPC_ERR_HIP, "host-to-device staging: %s", hipGetErrorString(e)); break; }
         const int64_t chunk_bytes = ldpc_out_bytes(d->cfg.K, n, d->cfg.pack_mode);
         rc = ldpc_decode_device(d, sl.llr.p, n, sl.out.p, chunk_bytes, iters ? sl.iters.p : nullptr, d->stream);
@@ -1020,12 +1028,12 @@ int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
         if (e != hipSuccess) { rc = fail(LDPC_ERR_HIP, "device-to-host staging: %s", hipGetErrorString(e)); break; }
         sl.busy = true;
     }
+    const int64_t k = ngroups;
     for (int i = 0; i < nslots; ++i) {          /* oldest first: slot (k % nslots) was filled earliest */
         const int r2 = drain(d->slot[(k + i) % nslots]);
         if (rc == LDPC_OK) rc = r2;
     }
     for (void *p : pinned) (void)hipHostUnregister(p);
-    d->suppress_poll = false;
     return rc;
 }
 
