@@ -84,11 +84,14 @@ typedef struct ldpc_decoder_config {
     int32_t early_term;     /* 1: frames freeze when their syndrome is clean (reference
                                behaviour, decodeCL.c:27,48-49); 0: always run max_iter      */
     int32_t device;         /* HIP device ordinal                                          */
-    int32_t layer_rows;     /* LDPC_ALGO_LAYERED / MS_FUSED: rows per layer = circulant size z */
+    int32_t layer_rows;     /* rows per layer = circulant size z.  Required for LDPC_ALGO_LAYERED / MS_FUSED; with
+                               SP / MS it lets the one-launch kernels for quasi-cyclic codes apply (0: streaming) */
     int32_t pack_mode;      /* enum ldpc_pack_mode                                         */
     int32_t frames_per_lane;/* tuning: 0 = auto, else 1, 2 or 4 (tile = 64*frames_per_lane) */
     int32_t poll_interval;  /* early_term: host checks "all frames done" every this many
-                               iterations (0 = never; finished tiles still skip on device)  */
+                               iterations (0 = never; finished tiles still skip on device).
+                               With polling on, the last <= 512 running frames of a multi-tile
+                               batch are handed to a small child decoder (tail compaction)   */
     int32_t reserved[8];    /* must be 0                                                   */
 } ldpc_decoder_config;
 
