@@ -180,6 +180,13 @@ def test_counter_based_channel_generator(tmp_path):
     lib.normals(20260101, 3, 16, a.ctypes.data_as(ctypes.c_void_p))
     lib.normals(20260101, 4, 16, b.ctypes.data_as(ctypes.c_void_p))
     assert np.array_equal(a, z[:64]) and not np.array_equal(a, b)
+    # the oracle's host evaluation (bench.py's CPU-baseline inputs) is the same function
+    import oracle
+    bits = np.random.default_rng(3).integers(0, 2, (3, 67)).astype(np.uint8)
+    want = np.empty((3, 67), np.float32)
+    lib.awgn(want.ctypes.data_as(ctypes.c_void_p), 3, 67, bits.ctypes.data_as(ctypes.c_void_p), 0.7, 9, 5)
+    assert np.array_equal(oracle.awgn(67, 5, 3, 0.7, seed=9, codewords=bits).view(np.uint32), want.view(np.uint32))
+    assert abs(float(oracle.awgn(64800, 0, 2, 0.95).mean()) - 1.0) < 0.01
 
 
 # ------------------------------------------------------------- oracle vs reference
