@@ -9,27 +9,32 @@ codeword + AWGN at sigma = 0.95: no frame's syndrome becomes clean, so all 50 ro
 full work with the reference's freeze-on-clean-syndrome semantics switched ON.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1: launched by torch.distributed.run, one rank per GPU (RCCL); frames shard
-across ranks with no exchange while decoding, the decoded bytes are all-gathered at the
-end of every step (weak scaling: 4096 frames per GPU).
+
+N > 1: one rank per GPU (torch.distributed, backend "nccl" = RCCL).  Invoked plainly
+(`python bench.py --gpus N`, no WORLD_SIZE in the environment) this script starts the N
+ranks itself -- as fresh child processes of `python -m torch.distributed.run`, before
+anything in this process touches the GPU -- relays rank 0's JSON line and exits with the
+children's status; invoked under torch.distributed.run it is one of the ranks.  Frames
+shard across ranks with no exchange while decoding; the decoded bytes are all-gathered at
+the end of every step (weak scaling: 4096 frames per GPU).
 
 Prints ONE JSON line (rank 0): metric/value/unit (whole-job Mbit/s), ms_per_step,
-`roofline` for the dominant kernel (HIP-event time on the launch stream, live), and --
-at N = 1 -- `cpu_baseline`: the oracle's restatement of the reference's CPU decoder
-(min-sum, MyLdpc.cpp:684-784) timed on the host cores on a bounded sample.
+`roofline` for the dominant kernel (HIP-event time on the launch stream, live) and, at
+N = 1, `cpu_baseline` (the oracle's restatement of the reference's CPU decoder,
+MyLdpc.cpp:684-784, on a bounded sample), `extra` (BASELINE.json configs[3] and [4] at
+their full batch sizes) and `host_path` (the reference's own signature: host buffers in,
+host buffers out, PCIe included).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 N_CODE, K_CODE = 64800, 32400
 BATCH_PER_GPU = 4096
@@ -38,8 +43,8 @@ SIGMA = 0.95
 SEED = 20260101
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
-# Extra measurement points (BASELINE.json configs[3], configs[4]); NOT the headline line.
-#   python bench.py --config bg1_layered | dvbs2_910_f16
+# Extra measurement points (BASELINE.json configs[3], configs[4]); reported under "extra" of the
+# headline line at N = 1, or alone with   python bench.py --config bg1_layered | dvbs2_910_f16
 EXTRA_CONFIGS = {
     "bg1_layered": dict(desc="5G-NR BG1-profile QC code, Z=384 (N=26112, K=8448, E=121344), batch 8192, "
                              "layered min-sum fp32, 20 iterations, sigma=1.1 (no frame converges)",
@@ -51,10 +56,12 @@ EXTRA_CONFIGS = {
 }
 
 
-def run_extra(name, args):
-    """One JSON line for an extra config (single GPU)."""
+def measure_extra(name, steps, warmup, batch=0, sigma=0.0, fpl=0):
+    """One extra config on the current GPU: dict with the headline fields of its own."""
+    import numpy as np
+    import torch
     import myldpccppapi_amd as L
-    from myldpccppapi_amd import codes
+    from myldpccppapi_amd import channel, codes
     c = EXTRA_CONFIGS[name]
     if name == "bg1_layered":
         Z = 384
@@ -66,27 +73,26 @@ def run_extra(name, args):
         rows, cols = codes.dvbs2_profile_edges(N, K)
         M, layer = N - K, 0
         bytes_fi = 8 * len(rows) + 2 * N
-    B = args.batch or c["batch"]
-    if args.sigma:
-        c = dict(c, sigma=args.sigma, desc=c["desc"] + " [sigma override %.3f]" % args.sigma)
+    B = batch or c["batch"]
+    if sigma:
+        c = dict(c, sigma=sigma, desc=c["desc"] + " [sigma override %.3f]" % sigma)
     g = L.Graph(rows, cols, M, N)
     dec = L.Decoder(g, K, max_batch=B, algo=c["algo"], max_iter=c["iters"], early_term=c["early"],
-                    layer_rows=layer, msg_dtype=c["msg"], poll_interval=c["poll"], frames_per_lane=args.fpl)
-    from myldpccppapi_amd import channel
+                    layer_rows=layer, msg_dtype=c["msg"], poll_interval=c["poll"], frames_per_lane=fpl)
     y = channel.awgn_device(N, 0, B, c["sigma"], seed=SEED)
     out = torch.empty(L.out_bytes(K, B), dtype=torch.uint8, device="cuda")
     it = torch.empty(B, dtype=torch.int32, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         dec.decode_device(y.data_ptr(), B, out.data_ptr(), out.numel(), it.data_ptr(), s)
     torch.cuda.synchronize()
     dec.set_timing(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         dec.decode_device(y.data_ptr(), B, out.data_ptr(), out.numel(), it.data_ptr(), s)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    dt = (time.perf_counter() - t0) / steps
     st = dec.stats()
     kt = [k for k in dec.kernel_times() if k["phase"] in (0, 1, 2)]
     iters = it.cpu().numpy()
@@ -99,9 +105,9 @@ def run_extra(name, args):
         # LDS / cache resident decode: the kernel's HBM traffic is the channel values and the packed
         # bits only; `achieved` stays SURVEY section 8(d)'s algorithmic figure of the schedule
         # (16 E bytes per frame-iteration) over the kernel's time, so it can exceed the HBM peak
-        kb = bytes_fi * frame_iters * args.steps
+        kb = bytes_fi * frame_iters * steps
     res = {"metric": "decoded Mbit/s (info bits)", "value": round(B * K / dt / 1e6, 2), "unit": "Mbit/s",
-           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),
+           "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 3),
            "higher_is_better": True, "dtype": "f16" if c["msg"] == "f16" else "f32", "data": "synthetic",
            "config": {"workload": c["desc"], "frames": B, "rounds_launched": st["iterations_launched"],
                       "avg_iterations_per_frame": round(frame_iters / B, 2),
@@ -119,16 +125,43 @@ def run_extra(name, args):
         res["roofline"]["note"] = ("one launch, frame state in LDS and check records in L2/Infinity Cache: "
                                    "achieved = algorithmic bytes of the layered schedule / kernel time, not HBM traffic")
         res["roofline"]["hbm_bytes_per_launch"] = int(hbm_moved / max(1, kt[0]["launches"]))
-    print(json.dumps(res), flush=True)
     dec.close()
+    del y, out, it
+    torch.cuda.empty_cache()
+    return res
+
+
+def host_path(g, groups=3, B=BATCH_PER_GPU):
+    """The reference's own signature (`Coder::decode` -> `ldpc_decode`): host buffers in, host
+    buffers out, `groups` x B frames, sum-product at full work -- PCIe transfers included."""
+    import torch
+    import myldpccppapi_amd as L
+    from myldpccppapi_amd import channel
+    frames = groups * B
+    y_host = torch.empty((frames, N_CODE), dtype=torch.float32)         # pageable, as a caller's malloc
+    for k in range(groups):
+        y_host[k * B:(k + 1) * B] = channel.awgn_device(N_CODE, k * B, B, SIGMA, seed=SEED).cpu()
+    torch.cuda.empty_cache()
+    dec = L.Decoder(g, K_CODE, max_batch=B, algo="sp", max_iter=ITERS, llr_scale=8.0, early_term=True)
+    ynp = y_host.numpy()
+    dec.decode(ynp[:64], want_iters=False)                                # staging slots, first-touch
+    t0 = time.perf_counter()
+    out, _ = dec.decode(ynp, want_iters=False)
+    dt = time.perf_counter() - t0
+    dec.close()
+    return {"value": round(frames * K_CODE / dt / 1e6, 2), "unit": "Mbit/s", "frames": frames,
+            "ms": round(dt * 1e3, 2), "max_batch": B,
+            "what": "ldpc_decode (Coder::decode's signature): %d frames from pageable host memory in %d groups of %d, "
+                    "sum-product fp32, %d iterations at full work, packed bytes back in host memory; H2D of group "
+                    "k+1 and D2H of group k-1 overlap the decode of group k" % (frames, groups, B, ITERS)}
 
 
 def cpu_baseline(rows, cols, seconds_budget=20.0, gpu_graph=None, gpu_y=None):
     """Reference CPU decode (min-sum, MyLdpc.cpp:684-784) via the oracle port, all host
     cores (frames split over threads; the C call releases the GIL) and one core."""
     from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
     import oracle
-    from myldpccppapi_amd import channel
     M = N_CODE - K_CODE
     g = oracle.Graph(rows, cols, M, N_CODE, K_CODE)
     try:
@@ -176,6 +209,30 @@ def cpu_baseline(rows, cols, seconds_budget=20.0, gpu_graph=None, gpu_y=None):
     }
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh children.  Nothing
+    in this process has touched the GPU (torch is not even imported yet)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it here
+    env["LDPC_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    for ln in p.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    if p.returncode != 0 or not lines:
+        sys.exit(p.returncode or 1)
+    sys.exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,18 +243,25 @@ def main():
                     help="dvbs2_sp = the headline workload (default); others are extra measurement points")
     ap.add_argument("--algo", default="sp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip `extra` and `host_path` (profiling runs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 flow on fewer GPUs than ranks (collectives on CPU copies)")
     ap.add_argument("--sigma", type=float, default=0.0, help="extra configs: noise level override")
     ap.add_argument("--fpl", type=int, default=0, help="frames per lane override (tuning)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(args.gpus, 1):
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
     rehearsal = args.backend == "gloo"
     if rehearsal:
         local_rank %= max(torch.cuda.device_count(), 1)
@@ -212,20 +276,20 @@ def main():
     if args.config != "dvbs2_sp":
         if world > 1:
             sys.exit("extra configs are single-GPU measurements")
-        return run_extra(args.config, args)
+        print(json.dumps(measure_extra(args.config, args.steps, args.warmup, args.batch, args.sigma, args.fpl)), flush=True)
+        return
 
     import myldpccppapi_amd as L
-    from myldpccppapi_amd import codes, sharding
+    from myldpccppapi_amd import channel, codes, sharding
 
     B = args.batch or BATCH_PER_GPU
     rows, cols = codes.dvbs2_profile_edges(N_CODE, K_CODE)
     g = L.Graph(rows, cols, N_CODE - K_CODE, N_CODE)
     dec = L.Decoder(g, K_CODE, max_batch=B, algo=args.algo, max_iter=ITERS, llr_scale=8.0,
-                    early_term=True, device=local_rank)
+                    early_term=True, device=local_rank, frames_per_lane=args.fpl)
     # synthetic channel: all-zero codeword + AWGN, generated in HBM, distinct per rank
     lo, hi = sharding.shard_range(B * world, rank, world)
     # (counter-based noise, csrc/ldpc_channel.h: frame lo + i of the seed's stream, whatever the world size)
-    from myldpccppapi_amd import channel
     y = channel.awgn_device(N_CODE, lo, B, SIGMA, seed=SEED, device=local_rank)
     out = torch.empty(L.out_bytes(K_CODE, B), dtype=torch.uint8, device="cuda")
     gathered = torch.empty(world * out.numel(), dtype=torch.uint8, device="cuda") if world > 1 else None
@@ -256,11 +320,19 @@ def main():
     for _ in range(args.steps):
         step()
     fence()
-    dt = time.perf_counter() - t0
+    dt_own = time.perf_counter() - t0
+    dt = dt_own
+    per_rank_ms = [dt_own / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([dt], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
+        dev = "cpu" if rehearsal else "cuda"
+        t = torch.tensor([dt_own], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        alls = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(alls, torch.tensor([dt_own], device=dev, dtype=torch.float64))
+        per_rank_ms = [float(a.item()) / args.steps * 1e3 for a in alls]
+        # the gathered bytes really are every rank's output: this rank's slice equals its own buffer
+        assert torch.equal(gathered[rank * out.numel():(rank + 1) * out.numel()], out)
 
     st = dec.stats()
     kt = dec.kernel_times()
@@ -271,17 +343,35 @@ def main():
         flood = [k for k in kt if k["phase"] in (0, 1)]
         dom = max(flood, key=lambda k: k["ms_total"])
         dom_avg_ms = dom["ms_total"] / dom["launches"]
-        dom_bytes = dom["bytes_total"] / dom["launches"]
+        # bytes the dominant kernel's own loads and stores move per launch (for the column-fused check
+        # kernel: less than its share of 16 E + 4 N, the fused columns' messages stay in registers) ...
+        dom_bytes = dom["bytes_moved"] / dom["launches"]
         achieved = dom_bytes / (dom_avg_ms * 1e-3) / 1e9
+        # ... and its share of SURVEY 8(d)'s two-kernel figure, for comparison
+        dom_alg = dom["bytes_total"] / dom["launches"]
         all_bytes = sum(k["bytes_total"] for k in flood)
+        all_moved = sum(k["bytes_moved"] for k in flood)
         all_ms = sum(k["ms_total"] for k in flood)
-        traffic = None
+        traffic, traffic_note = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom["name"])
+                tj = json.load(open(tpath))
+                tc = tj.get("__config__", {})
+                per = tj.get(dom["name"])
+                if per is not None and tc.get("frames_per_gpu"):
+                    traffic = int(per * B / tc["frames_per_gpu"])         # linear in the frames of a launch
+                    traffic_note = ("PMC FETCH_SIZE x2 + WRITE_SIZE per launch from %s (rocprofv3, separate passes, "
+                                    "%d frames per launch%s)" % (tc.get("source", "profiles/"), tc["frames_per_gpu"],
+                                                                 "" if tc["frames_per_gpu"] == B else ", scaled to %d" % B))
             except Exception:
                 traffic = None
+        probe = None
+        try:
+            probe = L.capi.hbm_probe(local_rank, 1 << 30, 5)
+        except Exception:
+            probe = None
+        step_alg = (16 * g.E + 4 * N_CODE) * ITERS * B
         res = {
             "metric": "decoded Mbit/s (info bits), DVB-S2 N=64800 rate-1/2, 50 iters",
             "value": round(value, 2), "unit": "Mbit/s", "n_gpus": world, "steps": args.steps,
@@ -298,25 +388,62 @@ def main():
                 "coded_mbit_s": round(value * N_CODE / K_CODE, 2),
                 "frames_converged": st["frames_converged"],
             },
+            "ranks": {"world_size": dist.get_world_size() if world > 1 else 1,
+                      "backend": ("gloo (rehearsal)" if rehearsal else "nccl (RCCL)") if world > 1 else None,
+                      "self_launched": os.environ.get("LDPC_BENCH_SELF_LAUNCHED") == "1",
+                      "ms_per_step_min": round(min(per_rank_ms), 3), "ms_per_step_max": round(max(per_rank_ms), 3)},
             "roofline": {
                 "bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": traffic_note,
                 "avg_launch_ms": round(dom_avg_ms, 4), "launches": dom["launches"],
-                "algorithmic_bytes_per_launch": int(dom_bytes),
+                "bytes_per_launch": int(dom_bytes),
+                "bytes_are": "what the kernel's own loads and stores move (every Q of its rows and the fused "
+                             "columns' channel values in, R of the unfused edges and the fused columns' new Q out)",
+                "two_kernel_formulation": {      # the same launch priced at its share of 16 E + 4 N
+                    "bytes_per_launch": int(dom_alg), "achieved": round(dom_alg / (dom_avg_ms * 1e-3) / 1e9, 1),
+                    "frac": round(dom_alg / (dom_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                "hbm_probe_gbs": None if probe is None else round(probe, 1),
+                "frac_of_probe": None if not probe else round(achieved / probe, 4),
                 "all_flooding_kernels": {
-                    "achieved": round(all_bytes / (all_ms * 1e-3) / 1e9, 1),
-                    "frac": round(all_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "moved_achieved": round(all_moved / (all_ms * 1e-3) / 1e9, 1),
+                    "moved_frac": round(all_moved / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "algorithmic_achieved": round(all_bytes / (all_ms * 1e-3) / 1e9, 1),
+                    "algorithmic_frac": round(all_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "bytes_per_frame_iteration": 16 * g.E + 4 * N_CODE,
+                    "moved_bytes_per_frame_iteration": int(all_moved / (dom["launches"] * B)),
                     "per_kernel": {k["name"]: {"avg_ms": round(k["ms_total"] / k["launches"], 4),
-                                               "GB/s": round(k["bytes_total"] / (k["ms_total"] * 1e-3) / 1e9, 1)}
+                                               "GB/s": round(k["bytes_moved"] / (k["ms_total"] * 1e-3) / 1e9, 1)}
                                    for k in flood},
                 },
-                "whole_step_frac": round((16 * g.E + 4 * N_CODE) * ITERS * B / (dt / args.steps) / 1e9
-                                         / HBM_PEAK_GBS, 4),
+                # (16 E + 4 N) x iterations x frames over the whole step's wall time
+                "whole_step_frac": round(step_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                "whole_step_frac_of_probe": None if not probe else round(step_alg / (dt / args.steps) / 1e9 / probe, 4),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(rows, cols, gpu_graph=g, gpu_y=y)
+        if world == 1 and not args.no_extras:
+            dec.close()
+            del y, out
+            torch.cuda.empty_cache()
+            extra = {}
+            for name, key in (("bg1_layered", "bg1_layered@8192"), ("dvbs2_910_f16", "dvbs2_910_f16@4096")):
+                try:
+                    r = measure_extra(name, steps=max(3, args.steps), warmup=2)
+                    extra[key] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                                  "dtype": r["dtype"], "workload": r["config"]["workload"],
+                                  "avg_iterations_per_frame": r["config"]["avg_iterations_per_frame"],
+                                  "frames_converged": r["config"]["frames_converged"],
+                                  "bit_errors_in_converged_frames": r["config"]["bit_errors_in_converged_frames"],
+                                  "roofline": r["roofline"]}
+                except Exception as e:      # an extra point must never cost the headline line
+                    extra[key] = {"error": repr(e)}
+            res["extra"] = extra
+            try:
+                res["host_path"] = host_path(g)
+            except Exception as e:
+                res["host_path"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
     dec.close()
     if world > 1:

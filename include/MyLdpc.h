@@ -25,6 +25,7 @@
  *     flooding kernel's arithmetic (decodeCL.c:432-567, 120 iterations as there).
  *   - `times` (MyLdpc.cpp:24) and the SP channel scale 8 (decodeCL.c:9) stay the
  *     defaults and can be changed with setMaxIterations()/setLlrScale().
+ *   - setDevices(): one Coder over several GPUs (the reference uses devices[0] only).
  */
 #ifndef MYLDPC_H_
 #define MYLDPC_H_
@@ -69,7 +70,12 @@ public:
     /* ---- additions ------------------------------------------------------ */
     void setMaxIterations(int times) { this->times = times; }   /* before addDecodeType */
     void setLlrScale(float s) { llrScale = s; }
-    void setDevice(int ordinal) { device = ordinal; }
+    void setDevice(int ordinal) { device = ordinal; devices.clear(); }
+    /* Several HIP devices behind one Coder (the reference opens devices[0] only, MyLdpc.cpp:235):
+     * decode() then cuts the frame stream into one contiguous range per entry and decodes the
+     * ranges side by side, batchSize frames per device and launch group; bytes identical to the
+     * single-device result.  Before addDecodeType(). */
+    void setDevices(const int *ordinals, int count) { devices.assign(ordinals, ordinals + (count > 0 ? count : 0)); }
     int lastIterations() const { return lastTime; }             /* the reference's "Time=" */
     const char *lastError() const { return err.c_str(); }
     int getNonZeros() const { return nonZeros; }
@@ -87,6 +93,8 @@ private:
     int times;
     float llrScale;
     int device;
+    std::vector<int> devices;        /* setDevices(); empty: `device` alone */
+    int makeDecoder(const ldpc_decoder_config &cfg, ldpc_decoder **out);
     const signed char *hSeed;
     int seedRowLength;
     int ldpcK, ldpcN, ldpcM, z, nonZeros, batchSize;

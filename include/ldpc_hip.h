@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define LDPC_HIP_ABI_VERSION 1
+#define LDPC_HIP_ABI_VERSION 2   /* 2: tuning fields in the config (were reserved[8]), device lists */
 
 enum ldpc_status {
     LDPC_OK = 0,
@@ -92,8 +92,37 @@ typedef struct ldpc_decoder_config {
                                iterations (0 = never; finished tiles still skip on device).
                                With polling on, the last <= 512 running frames of a multi-tile
                                batch are handed to a small child decoder (tail compaction)   */
-    int32_t reserved[8];    /* must be 0                                                   */
+    /* ---- tuning (was reserved[8]): 0 = automatic everywhere.  Kernel selection and launch
+     *      shapes only -- results never depend on these (the parity tests run the alternatives
+     *      against each other).  The library reads NO environment variables. ---------------- */
+    int32_t tune_flags;         /* LDPC_TUNE_* two-bit fields below: 0 auto, 1 force on, 2 force off */
+    int32_t tune_rows_per_wave; /* check kernels: rows per wave                                   */
+    int32_t tune_cols_per_wave; /* variable kernels: columns per wave                             */
+    int32_t tune_link_rows;     /* rows per wave of the column-fused check kernel (default 16; 4 for a
+                                   single tile); -1 = column-local fusion off                     */
+    int32_t tune_compact;       /* tail compaction: hand over when <= this many frames still run
+                                   (default and maximum 512); -1 = off                            */
+    int32_t tune_ldsp_grid;     /* record kernels (ldsp_kernels.hpp): persistent workgroups        */
+    int32_t tune_ldsp_shape;    /* workgroups per CU | waves per workgroup << 8                    */
+    int32_t reserved;           /* must be 0                                                       */
 } ldpc_decoder_config;
+
+/* two-bit fields of tune_flags: LDPC_TUNE_ON(f) forces the choice on, LDPC_TUNE_OFF(f) off */
+enum ldpc_tune_field {
+    LDPC_TUNE_FUSED = 0,        /* LDS-resident one-launch kernels (fused_kernels.hpp)              */
+    LDPC_TUNE_LDSP = 2,         /* record kernels: posteriors in LDS, check records in cache        */
+    LDPC_TUNE_LDSP_EXT = 4,     /* single-layer columns travel with the records (off: all in LDS)   */
+    LDPC_TUNE_LDSP_PACK = 6,    /* several frames per wave for circulants of <= 32 rows             */
+    LDPC_TUNE_LINK_NARROW = 8,  /* column-fused check kernel in narrow waves (default on)           */
+    LDPC_TUNE_CHECK_WIDE = 10,  /* check kernels move V floats per lane (default off)               */
+    LDPC_TUNE_SYN_XCD = 12,     /* XCD-aware syndrome grid (default on)                             */
+    LDPC_TUNE_FUSED_PACK = 14,  /* fused layered kernel: several frames per wave (default on)       */
+    LDPC_TUNE_FUSED_LOOP = 16,  /* fused kernels: run-time row loops instead of unrolled (default off) */
+    LDPC_TUNE_DEVICE_TAIL = 18  /* device-side early exit + tail compaction without host polling
+                                   (default: on when early_term && poll_interval == 0)              */
+};
+#define LDPC_TUNE_ON(field) (1 << (field))
+#define LDPC_TUNE_OFF(field) (2 << (field))
 
 typedef struct ldpc_decode_stats {
     int32_t iterations_launched; /* check/variable rounds enqueued by the last call          */
@@ -127,7 +156,22 @@ int ldpc_graph_info(const ldpc_graph *g, int32_t *M, int32_t *N, int64_t *E, int
  *      MyLdpc.cpp:226-305, 307-552 -------------------------------------------- */
 void ldpc_decoder_config_init(ldpc_decoder_config *cfg); /* reference defaults */
 int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldpc_decoder **out);
+/* The reference uses devices[0] of its context only (MyLdpc.cpp:226-235).  Here one handle may
+ * span several HIP devices: ldpc_decode() cuts the caller's frame stream into n_devices contiguous
+ * ranges (ldpc_shard_range), and one host thread per entry of devices[] runs that range through
+ * its own device decoder -- own stream, own pinned staging, results copied straight to the
+ * caller's buffers at the range's offsets; no exchange between devices (frames are independent).
+ * Bytes and iteration counts equal the single-device result.  An ordinal may appear more than
+ * once (two decoders sharing one GPU).  cfg->device is ignored; cfg->max_batch is per device.
+ * Device-pointer entry points (ldpc_decode_device, taps, dumps) need a single-device handle. */
+int ldpc_decoder_create_multi(const ldpc_graph *g, const ldpc_decoder_config *cfg, const int32_t *devices,
+                              int32_t n_devices, ldpc_decoder **out);
+/* Waits for this handle's own work only (its streams), not for the device. */
 int ldpc_decoder_destroy(ldpc_decoder *d);
+/* Frames [*lo, *hi) of part `part` of `parts` when `frames` frames are cut into contiguous, balanced
+ * ranges whose boundaries are multiples of `unit` frames (earlier parts take the remainder).  The
+ * same arithmetic shards frames over ranks in the benchmark (one process per GPU). */
+int ldpc_shard_range(int64_t frames, int32_t part, int32_t parts, int32_t unit, int64_t *lo, int64_t *hi);
 
 /* ---- decode: replaces Coder::decode + decodeOnceSP/MS/TDMP*, MyLdpc.cpp:571-618,
  *      786-1059.  Host buffers; chunks `frames` into max_batch groups; blocking.
@@ -161,11 +205,15 @@ typedef struct ldpc_kernel_time {
     int32_t degree;        /* row / column degree the kernel is specialised for        */
     int32_t launches;
     float ms_total;        /* sum of HIP-event durations of those launches             */
-    int64_t bytes_total;   /* ALGORITHMIC bytes of those launches: 4 B per message read
-                              or written + 4 B per channel value read, per frame        */
+    int64_t bytes_total;   /* ALGORITHMIC bytes of those launches in the two-kernel formulation
+                              (16 E + 4 N per frame-iteration over all kernels): 4 B per message
+                              read or written + 4 B per channel value read, per frame    */
     char name[64];         /* e.g. "check_link_kernel<sp,7,4>" (algo, degree, frames/lane), the
                               kernel's name in a rocprofv3 trace up to the spelling of the
                               template arguments                                        */
+    int64_t bytes_moved;   /* bytes those launches' own loads and stores move: = bytes_total except
+                              for the column-fused check kernel, whose fused columns' messages
+                              never travel through HBM (the figure the PMC counters confirm)  */
 } ldpc_kernel_time;
 int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t capacity,
                               int32_t *count);
@@ -195,6 +243,12 @@ int ldpc_awgn_device(float *llr_dev, int64_t frames, int32_t N, const uint8_t *b
                      uint64_t seed, int64_t first_frame, int32_t device, void *stream);
 int ldpc_count_errors_device(const uint8_t *out_dev, const uint8_t *ref_dev, int64_t frames,
                              int64_t bytes_per_frame, int64_t errors[3], int32_t device, void *stream);
+
+/* ---- measurement aid: the rate a plain float4 copy of `bytes` bytes (read + write counted)
+ *      sustains on `device` right now, best of `reps` launches, HIP-event timed on a stream of its
+ *      own.  The benchmark reports it next to its roofline figures so that a kernel's fraction of
+ *      the 8 TB/s specification can also be read against what the box at hand delivers. */
+int ldpc_hbm_probe_device(int32_t device, int64_t bytes, int32_t reps, double *copy_gbs);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,8 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# LDPC_HIP_LIB: load another build of the same library (kernel-variant experiments)
+# LDPC_HIP_LIB: load another build of the same library (kernel-variant experiments); read by this
+# Python loader only -- the library itself reads no environment variables
 LIB_PATH = os.environ.get("LDPC_HIP_LIB") or os.path.join(_HERE, "libldpc_hip.so")
 _lib = None
 
@@ -28,7 +29,11 @@ class DecoderConfig(ctypes.Structure):
                 ("llr_scale", ctypes.c_float), ("early_term", ctypes.c_int32),
                 ("device", ctypes.c_int32), ("layer_rows", ctypes.c_int32),
                 ("pack_mode", ctypes.c_int32), ("frames_per_lane", ctypes.c_int32),
-                ("poll_interval", ctypes.c_int32), ("reserved", ctypes.c_int32 * 8)]
+                ("poll_interval", ctypes.c_int32),
+                ("tune_flags", ctypes.c_int32), ("tune_rows_per_wave", ctypes.c_int32),
+                ("tune_cols_per_wave", ctypes.c_int32), ("tune_link_rows", ctypes.c_int32),
+                ("tune_compact", ctypes.c_int32), ("tune_ldsp_grid", ctypes.c_int32),
+                ("tune_ldsp_shape", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class DecodeStats(ctypes.Structure):
@@ -43,16 +48,17 @@ class DecodeStats(ctypes.Structure):
 class KernelTime(ctypes.Structure):
     """Mirror of `ldpc_kernel_time`."""
     _fields_ = [("phase", ctypes.c_int32), ("degree", ctypes.c_int32), ("launches", ctypes.c_int32),
-                ("ms_total", ctypes.c_float), ("bytes_total", ctypes.c_int64), ("name", ctypes.c_char * 64)]
+                ("ms_total", ctypes.c_float), ("bytes_total", ctypes.c_int64), ("name", ctypes.c_char * 64),
+                ("bytes_moved", ctypes.c_int64)]
 
 
 #: every symbol include/ldpc_hip.h declares
 EXPORTS = (
     "ldpc_abi_version", "ldpc_last_error", "ldpc_device_count", "ldpc_graph_create",
     "ldpc_graph_destroy", "ldpc_graph_info", "ldpc_decoder_config_init", "ldpc_decoder_create",
-    "ldpc_decoder_destroy", "ldpc_decode", "ldpc_decode_device", "ldpc_out_bytes",
+    "ldpc_decoder_create_multi", "ldpc_shard_range", "ldpc_decoder_destroy", "ldpc_decode", "ldpc_decode_device", "ldpc_out_bytes",
     "ldpc_decoder_set_timing", "ldpc_decoder_stats", "ldpc_decoder_kernel_times", "ldpc_decoder_set_tap",
-    "ldpc_decoder_dump", "ldpc_awgn_device", "ldpc_count_errors_device",
+    "ldpc_decoder_dump", "ldpc_awgn_device", "ldpc_count_errors_device", "ldpc_hbm_probe_device",
 )
 
 
@@ -86,6 +92,9 @@ def load():
     L.ldpc_decoder_config_init.argtypes = [ctypes.POINTER(DecoderConfig)]
     L.ldpc_decoder_config_init.restype = None
     L.ldpc_decoder_create.argtypes = [vp, ctypes.POINTER(DecoderConfig), ctypes.POINTER(vp)]
+    L.ldpc_decoder_create_multi.argtypes = [vp, ctypes.POINTER(DecoderConfig), i32p, ctypes.c_int32,
+                                            ctypes.POINTER(vp)]
+    L.ldpc_shard_range.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, i64p, i64p]
     L.ldpc_decoder_destroy.argtypes = [vp]
     L.ldpc_decode.argtypes = [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp]
     L.ldpc_decode_device.argtypes = [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, vp]
@@ -99,6 +108,8 @@ def load():
     L.ldpc_awgn_device.argtypes = [vp, ctypes.c_int64, ctypes.c_int32, vp, ctypes.c_float, ctypes.c_uint64,
                                    ctypes.c_int64, ctypes.c_int32, vp]
     L.ldpc_count_errors_device.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, i64p, ctypes.c_int32, vp]
+    L.ldpc_hbm_probe_device.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32,
+                                        ctypes.POINTER(ctypes.c_double)]
     _lib = L
     return L
 

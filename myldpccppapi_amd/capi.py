@@ -16,6 +16,70 @@ MSG_F32, MSG_F16 = 0, 1
 PACK_BYTES, PACK_BITS = 0, 1
 ALGOS = {"sp": ALGO_SP, "ms": ALGO_MS, "layered": ALGO_LAYERED, "ms_fused": ALGO_MS_FUSED}
 
+# two-bit fields of ldpc_decoder_config.tune_flags (enum ldpc_tune_field): True forces on, False off
+TUNE_FIELDS = {"fused": 0, "ldsp": 2, "ldsp_ext": 4, "ldsp_pack": 6, "link_narrow": 8, "check_wide": 10,
+               "syn_xcd": 12, "fused_pack": 14, "fused_loop": 16, "device_tail": 18}
+TUNE_INTS = ("rows_per_wave", "cols_per_wave", "link_rows", "compact", "ldsp_grid", "ldsp_per_cu", "ldsp_waves")
+
+
+def apply_tune(cfg, tune):
+    """Fill the tuning fields of a DecoderConfig from a dict: tri-state names of TUNE_FIELDS
+    (True / False / None = automatic) and integers of TUNE_INTS (link_rows=-1: column-local fusion
+    off; compact=-1: tail compaction off).  Kernel selection and launch shapes only."""
+    flags, shape = 0, 0
+    for k, v in (tune or {}).items():
+        if k in TUNE_FIELDS:
+            if v is not None:
+                flags |= (1 if v else 2) << TUNE_FIELDS[k]
+        elif k == "ldsp_per_cu":
+            shape |= int(v) & 255
+        elif k == "ldsp_waves":
+            shape |= (int(v) & 255) << 8
+        elif k in TUNE_INTS:
+            setattr(cfg, "tune_" + k, int(v))
+        else:
+            raise KeyError("unknown tuning field %r" % k)
+    cfg.tune_flags, cfg.tune_ldsp_shape = flags, shape
+
+
+def hbm_probe(device=0, nbytes=1 << 30, reps=5):
+    """GB/s of a plain float4 copy on `device` (read + write), best of `reps`."""
+    g = ctypes.c_double(0.0)
+    _lib.check(_lib.load().ldpc_hbm_probe_device(int(device), int(nbytes), int(reps), ctypes.byref(g)))
+    return g.value
+
+
+def tune_from_env(env=None):
+    """For the measurement scripts under tools/: translate LDPC_TUNE_* environment switches into
+    a tuning dict for Decoder(tune=...).  The library itself reads no environment variables."""
+    import os
+    env = os.environ if env is None else env
+    t = {}
+    for name, key in (("FUSED", "fused"), ("LDSP", "ldsp"), ("LDSP_EXT", "ldsp_ext"), ("LDSP_PACK", "ldsp_pack"),
+                      ("LINK_NARROW", "link_narrow"), ("CHECK_WIDE", "check_wide"), ("SYN_XCD", "syn_xcd"),
+                      ("FUSED_LOOP", "fused_loop"), ("DEVICE_TAIL", "device_tail")):
+        if "LDPC_TUNE_" + name in env:
+            t[key] = int(env["LDPC_TUNE_" + name]) != 0
+    if "LDPC_TUNE_NO_PACK" in env:
+        t["fused_pack"] = False
+    for name, key in (("RPW", "rows_per_wave"), ("CPW", "cols_per_wave"), ("LDSP_GRID", "ldsp_grid"),
+                      ("LDSP_PER_CU", "ldsp_per_cu"), ("LDSP_WAVES", "ldsp_waves")):
+        if "LDPC_TUNE_" + name in env:
+            t[key] = int(env["LDPC_TUNE_" + name])
+    for name, key in (("LINK_RPW", "link_rows"), ("COMPACT", "compact")):     # 0 meant "off"
+        if "LDPC_TUNE_" + name in env:
+            v = int(env["LDPC_TUNE_" + name])
+            t[key] = v if v > 0 else -1
+    return t
+
+
+def shard_range(frames, part, parts, unit=1):
+    """ldpc_shard_range: frames [lo, hi) of part `part` of `parts` (boundaries multiples of `unit`)."""
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    _lib.check(_lib.load().ldpc_shard_range(int(frames), int(part), int(parts), int(unit),
+                                            ctypes.byref(lo), ctypes.byref(hi)))
+    return lo.value, hi.value
+
 
 def device_count():
     n = ctypes.c_int(0)
@@ -69,7 +133,7 @@ class Decoder:
 
     def __init__(self, graph, K, max_batch, algo="sp", max_iter=40, llr_scale=8.0, early_term=True,
                  device=0, layer_rows=0, pack_mode=PACK_BYTES, frames_per_lane=0, poll_interval=0,
-                 msg_dtype=MSG_F32):
+                 msg_dtype=MSG_F32, tune=None, devices=None):
         L = _lib.load()
         cfg = DecoderConfig()
         L.ldpc_decoder_config_init(ctypes.byref(cfg))
@@ -79,11 +143,17 @@ class Decoder:
         cfg.max_iter, cfg.llr_scale = int(max_iter), float(llr_scale)
         cfg.early_term, cfg.device, cfg.layer_rows = int(bool(early_term)), int(device), int(layer_rows)
         cfg.pack_mode, cfg.frames_per_lane, cfg.poll_interval = int(pack_mode), int(frames_per_lane), int(poll_interval)
+        apply_tune(cfg, tune)
         self.cfg = cfg
         self.graph = graph
         self.K, self.N, self.E = int(K), graph.N, graph.E
         self._h = ctypes.c_void_p()
-        _lib.check(L.ldpc_decoder_create(graph._h, ctypes.byref(cfg), ctypes.byref(self._h)))
+        if devices is None:
+            _lib.check(L.ldpc_decoder_create(graph._h, ctypes.byref(cfg), ctypes.byref(self._h)))
+        else:       # one handle over several devices (ldpc_decoder_create_multi): host-buffer decode only
+            devs = (ctypes.c_int32 * len(devices))(*[int(x) for x in devices])
+            _lib.check(L.ldpc_decoder_create_multi(graph._h, ctypes.byref(cfg), devs, len(devices),
+                                                   ctypes.byref(self._h)))
 
     # -- host buffers (the reference's Coder::decode signature) -------------
     def decode(self, llr, want_iters=True):
@@ -117,7 +187,8 @@ class Decoder:
         n = ctypes.c_int32(0)
         _lib.check(_lib.load().ldpc_decoder_kernel_times(self._h, arr, 64, ctypes.byref(n)))
         return [dict(name=arr[i].name.decode(), phase=arr[i].phase, degree=arr[i].degree,
-                     launches=arr[i].launches, ms_total=arr[i].ms_total, bytes_total=arr[i].bytes_total)
+                     launches=arr[i].launches, ms_total=arr[i].ms_total, bytes_total=arr[i].bytes_total,
+                     bytes_moved=arr[i].bytes_moved)
                 for i in range(n.value)]
 
     def set_tap(self, it):

@@ -138,18 +138,21 @@ int Coder::forEncoder()
     return LDPC_SUCCESS;
 }
 
-/* encode, MyLdpc.cpp:554-569: frame f reads srcCode + f*K/8 and writes priorCode
- * + f*N/8; the last frame may be short (zero-padded, :639-650). */
+/* encode, MyLdpc.cpp:554-569, index for index: frame f reads srcCode + f*K/8 (integer division
+ * of the PRODUCT, as the decoders write frame f at (f*K)/8, decodeCL.c:191-192) and writes
+ * priorCode + f*N/8; the last frame may be short (zero-padded, :639-650).  For K % 8 != 0 --
+ * e.g. Coder(324, 648, rate_1_2) -- frames therefore start at bytes 0, 40, 81, 121, ...: every
+ * other frame skips one source byte, exactly as in the reference. */
 int Coder::encode(char *srcCode, char *priorCode, int srcLength)
 {
     if (!isEncoder) return fail(LDPC_ERR_STATE, "encode: call forEncoder() first");
     if (!srcCode || !priorCode || srcLength <= 0) return fail(LDPC_ERR_ARG, "encode: bad arguments");
     for (int offset = 0;; ++offset) {
-        if ((offset + 1) * (ldpcK / 8) < srcLength) {
-            encodeOnce(&srcCode[offset * (ldpcK / 8)], &priorCode[offset * (ldpcN / 8)], ldpcK / 8);
-        } else {
-            encodeOnce(&srcCode[offset * (ldpcK / 8)], &priorCode[offset * (ldpcN / 8)],
-                       srcLength - offset * (ldpcK / 8));
+        const int at = (int)((long long)offset * ldpcK / 8);
+        if ((long long)(offset + 1) * ldpcK / 8 < srcLength) {           /* not the last, :557 */
+            encodeOnce(&srcCode[at], &priorCode[(long long)offset * ldpcN / 8], ldpcK / 8);
+        } else {                                                          /* the last, :561-565 */
+            encodeOnce(&srcCode[at], &priorCode[(long long)offset * ldpcN / 8], srcLength - at);
             break;
         }
     }
@@ -192,6 +195,8 @@ int Coder::encodeOnce(const char *src, char *code, int srcLength)
     }
     /* the reference copies the source with strncpy (:661), which stops at a NUL
      * byte; the intent -- and this code -- is a plain copy */
+    if (srcLength < 0) srcLength = 0;
+    if (srcLength > ldpcK / 8) srcLength = ldpcK / 8;
     memcpy(code, src, (size_t)srcLength);
     memset(code + srcLength, 0, (size_t)(ldpcN / 8 - srcLength));
     for (int i = 0; i < ldpcM; ++i)
@@ -219,6 +224,13 @@ int Coder::forDecoder(int batchSize)
     return LDPC_SUCCESS;
 }
 
+/* one device (setDevice) or a device list (setDevices) behind the handle */
+int Coder::makeDecoder(const ldpc_decoder_config &cfg, ldpc_decoder **out)
+{
+    if (devices.empty()) return ldpc_decoder_create(graph, &cfg, out);
+    return ldpc_decoder_create_multi(graph, &cfg, devices.data(), (int)devices.size(), out);
+}
+
 /* addDecodeType, MyLdpc.cpp:307-552. */
 int Coder::addDecodeType(enum decodeType deType)
 {
@@ -240,7 +252,7 @@ int Coder::addDecodeType(enum decodeType deType)
                : (deType == DecodeMSCL) ? LDPC_ALGO_MS_FUSED : LDPC_ALGO_LAYERED;
     if (deType == DecodeMSCL) cfg.max_iter = 120;      /* hard-coded in the reference kernel, decodeCL.c:479 */
     ldpc_decoder *d = nullptr;
-    int rc = ldpc_decoder_create(graph, &cfg, &d);
+    int rc = makeDecoder(cfg, &d);
     if (rc) return fail(rc, ldpc_last_error());
     decoders[(int)deType] = d;
     return LDPC_SUCCESS;
@@ -264,7 +276,7 @@ int Coder::decode(float *postCode, char *srcCode, int srcLength, enum decodeType
             cfg.K = ldpcK; cfg.max_batch = codeSize; cfg.max_iter = times; cfg.device = device;
             cfg.algo = LDPC_ALGO_MS; cfg.pack_mode = LDPC_PACK_BITS; cfg.early_term = 1; cfg.poll_interval = 4;
             cfg.layer_rows = z;                              /* circulant size: lets the one-launch kernels apply */
-            int rc = ldpc_decoder_create(graph, &cfg, &d);
+            int rc = makeDecoder(cfg, &d);
             if (rc) return fail(rc, ldpc_last_error());
             decoders[(int)DecodeCPU] = d;
             cpuDecoderBatch = codeSize;

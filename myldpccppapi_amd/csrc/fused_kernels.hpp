@@ -35,6 +35,7 @@
 
 #include "layered_kernels.hpp"
 #include "ldpc_expf.h"
+#include "tune.hpp"
 
 namespace ldpc {
 
@@ -849,6 +850,8 @@ struct FusedRun {
     int32_t flooding;   /* 0: layered (decodeOnceTDMP), 1: flooding (decodeOnceMS), 2: flooding with the MS chain's
                            arithmetic, 3: sum-product */
     float llr_scale;
+    int32_t loop_rows;  /* tuning: run-time row loops instead of the unrolled widths */
+    int32_t no_pack;    /* tuning: one frame per wave also for circulants of <= 32 rows */
 };
 
 inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int32_t *launched)
@@ -875,7 +878,7 @@ inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int
     const int mw = (pl->z + 63) / 64;
     const unsigned grid = (unsigned)r.frames;
     /* DMAX: unrolled row width (8 / 16 / 24), 0 = run-time loops for anything wider */
-    const int dm = getenv("LDPC_TUNE_FUSED_LOOP") ? 0 : (pl->max_deg <= 8 ? 8 : pl->max_deg <= 16 ? 16 : pl->max_deg <= 24 ? 24 : 0);
+    const int dm = r.loop_rows ? 0 : (pl->max_deg <= 8 ? 8 : pl->max_deg <= 16 ? 16 : pl->max_deg <= 24 ? 24 : 0);
 #define LDPC_FUSED_LAUNCH(KERNEL, MWV, ...)                                                      \
     do {                                                                                         \
         if (dm == 8) KERNEL<MWV, 8 __VA_ARGS__><<<grid, 64 * MWV, pl->lds_per_frame, s>>>(a);    \
@@ -912,7 +915,7 @@ inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int
         LDPC_FUSED_BY_MW(fused_flood_kernel, LDPC_COMMA true)
     } else if (r.flooding) {
         LDPC_FUSED_BY_MW(fused_flood_kernel, LDPC_COMMA false)
-    } else if (pl->z <= 32 && !getenv("LDPC_TUNE_NO_PACK")) {
+    } else if (pl->z <= 32 && !r.no_pack) {
         int G = 64 / pl->z;
         while (G > 1 && (size_t)G * pl->lds_per_frame > 60 * 1024) --G;   /* default dynamic-LDS limit */
         const unsigned pgrid = (unsigned)((r.frames + G - 1) / G);

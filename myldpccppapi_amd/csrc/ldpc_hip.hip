@@ -27,6 +27,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ldpc_hip.h"
@@ -35,6 +36,7 @@
 #include "fused_kernels.hpp"
 #include "ldsp_kernels.hpp"
 #include "channel_kernels.hpp"
+#include "tune.hpp"
 
 namespace {
 
@@ -173,7 +175,8 @@ struct TimedSpan {
     hipEvent_t a, b;
     int kind;       /* 0 check, 1 var, 2 layer, 3 other, 4 check with column-local fusion */
     int degree;
-    int64_t bytes;  /* algorithmic bytes of the launch */
+    int64_t bytes;  /* algorithmic bytes of the launch in the two-kernel formulation (16 E + 4 N in total) */
+    int64_t moved;  /* bytes this kernel's own loads and stores move (less when columns are fused in) */
 };
 
 }  // namespace
@@ -198,7 +201,8 @@ struct ldpc_decoder {
     int max_check_unrolled = ldpc::kMaxUnrolledDegree;
     LinkFn link_fn[ldpc::kMaxUnrolledDegree + 1] = {};        /* wide waves */
     LinkFn link_narrow_fn[ldpc::kMaxUnrolledDegree + 1] = {}; /* narrow waves */
-    int tune_link_narrow = 1;           /* LDPC_TUNE_LINK_NARROW=0: wide linked check kernel */
+    ldpc::Tune tune;                    /* cfg.tune_* unpacked (tune.hpp) */
+    int tune_link_narrow = 1;           /* 0: wide linked check kernel */
     int link_rpw = 16;                  /* rows per wave of the fused check kernel; 0 = fusion off */
     VarFn var_fn[ldpc::kMaxUnrolledDegree + 1] = {};
 
@@ -227,7 +231,7 @@ struct ldpc_decoder {
      * frames of a polled, early-terminating decode */
     ldpc_decoder *child = nullptr;
     DevBuf<int32_t> cmap;               /* [kCompactCapacity] frame indices handed to the child */
-    int compact_threshold = ldpc::kCompactCapacity;   /* LDPC_TUNE_COMPACT: 0 = off, else hand over when <= this many frames run */
+    int compact_threshold = ldpc::kCompactCapacity;   /* cfg.tune_compact: 0 = off, else hand over when <= this many frames run */
     bool is_child = false;
 
     bool timing = false;                /* the call being enqueued is timed */
@@ -239,15 +243,20 @@ struct ldpc_decoder {
     hipStream_t last_stream = nullptr;
     bool have_last = false;
     int32_t tap_iter = 0;
-    int tune_rpw = 0, tune_cpw = 0;     /* LDPC_TUNE_RPW / LDPC_TUNE_CPW: rows / columns per wave */
-    int tune_syn_xcd = 1;               /* LDPC_TUNE_SYN_XCD=0: plain 2-D syndrome grid */
-    int tune_check_wide = 0;            /* LDPC_TUNE_CHECK_WIDE=1: check kernels move V floats per lane */
+    int tune_rpw = 0, tune_cpw = 0;     /* rows / columns per wave (0 = automatic) */
+    int tune_syn_xcd = 1;               /* 0: plain 2-D syndrome grid */
+    int tune_check_wide = 0;            /* 1: check kernels move V floats per lane */
     int32_t last_iterations = 0;
     int64_t last_frames = 0;
     DevBuf<int32_t> summary;            /* [2]: max iters, converged count */
 
+    /* a handle over several devices (ldpc_decoder_create_multi): one single-device decoder per entry
+     * of the device list; this object then owns no device state of its own */
+    std::vector<ldpc_decoder *> shards;
+
     ~ldpc_decoder()
     {
+        for (ldpc_decoder *sh : shards) (void)ldpc_decoder_destroy(sh);
         for (auto &s : spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
         if (ev_begin) (void)hipEventDestroy(ev_begin);
         if (ev_end) (void)hipEventDestroy(ev_end);
@@ -297,7 +306,7 @@ int pick_frames_per_lane(const ldpc_decoder_config &cfg, int32_t max_row_deg, in
     return 1;
 }
 
-hipError_t span_begin(ldpc_decoder *d, hipStream_t s, int kind, int degree = 0, int64_t bytes = 0)
+hipError_t span_begin(ldpc_decoder *d, hipStream_t s, int kind, int degree = 0, int64_t bytes = 0, int64_t moved = -1)
 {
     if (!d->timing) return hipSuccess;
     if (d->spans_used == d->spans.size()) {
@@ -311,6 +320,7 @@ hipError_t span_begin(ldpc_decoder *d, hipStream_t s, int kind, int degree = 0, 
     d->spans[d->spans_used].kind = kind;
     d->spans[d->spans_used].degree = degree;
     d->spans[d->spans_used].bytes = bytes;
+    d->spans[d->spans_used].moved = moved < 0 ? bytes : moved;
     return hipEventRecord(d->spans[d->spans_used].a, s);
 }
 
@@ -390,8 +400,13 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
         for (auto &rc : d->row_classes) {
             /* algorithmic bytes: the fused columns' messages and channel values count as in the
              * two-kernel formulation (16 E + 4 N per frame-iteration in total) */
+            /* moved: every Q of the class and the fused columns' channel values in; R of the unfused
+             * edges and the fused columns' new Q out */
             HIP_TRY(span_begin(d, s, rc.linked ? 4 : 0, rc.degree,
-                               (2 * msz * rc.degree * rc.count + msz * 5 * rc.linked) * frames));
+                               (2 * msz * rc.degree * rc.count + msz * 5 * rc.linked) * frames,
+                               msz * ((int64_t)rc.degree * rc.count + rc.linked +
+                                      ((int64_t)rc.degree * rc.count - 2 * rc.linked) +
+                                      (it < max_iter ? 2 * rc.linked : 0)) * frames));
             CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree};
             if (rc.linked) {
                 LinkArgs lk{rc.link_col.p, rc.link_pos.p, d->chan.p, d->Q.p, d->hard.p, d->N,
@@ -717,8 +732,7 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     if (cfg->msg_dtype == LDPC_MSG_F16 && cfg->algo != LDPC_ALGO_MS)
         return fail(LDPC_ERR_UNSUPPORTED, "fp16 messages are built for flooding min-sum only "
                     "(the probability-domain SP needs fp32 range; layered: not yet)");
-    for (int i = 0; i < 8; ++i)
-        if (cfg->reserved[i]) return fail(LDPC_ERR_ARG, "reserved config fields must be 0");
+    if (!ldpc::tune_valid(*cfg)) return fail(LDPC_ERR_ARG, "tuning / reserved config fields out of range");
 
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -732,18 +746,19 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     d->cfg = *cfg;
     d->M = g->M; d->N = g->N; d->E = g->E;
     d->h_col_ptr = g->col_ptr; d->h_col_edge = g->col_edge; d->h_rows = g->rows; d->h_cols = g->cols;
-    if (const char *e = getenv("LDPC_TUNE_RPW")) d->tune_rpw = atoi(e);
-    if (const char *e = getenv("LDPC_TUNE_CPW")) d->tune_cpw = atoi(e);
-    if (const char *e = getenv("LDPC_TUNE_SYN_XCD")) d->tune_syn_xcd = atoi(e);
-    if (const char *e = getenv("LDPC_TUNE_CHECK_WIDE")) d->tune_check_wide = atoi(e);
-    if (const char *e = getenv("LDPC_TUNE_LINK_RPW")) d->link_rpw = atoi(e);
-    if (const char *e = getenv("LDPC_TUNE_LINK_NARROW")) d->tune_link_narrow = atoi(e);
+    const ldpc::Tune tune = d->tune = ldpc::tune_from_config(*cfg);
+    d->tune_rpw = tune.rows_per_wave;
+    d->tune_cpw = tune.cols_per_wave;
+    d->tune_syn_xcd = ldpc::tune_pick(tune.syn_xcd, true);
+    d->tune_check_wide = ldpc::tune_pick(tune.check_wide, false);
+    d->tune_link_narrow = ldpc::tune_pick(tune.link_narrow, true);
+    if (tune.link_rows) d->link_rpw = tune.link_rows < 0 ? 0 : tune.link_rows;
     d->V = pick_frames_per_lane(*cfg, g->max_row_deg, g->max_col_deg);
     d->F = 64 * d->V;
     d->T = (cfg->max_batch + d->F - 1) / d->F;
     /* a single tile is latency-bound (one wave walks its rows one after the other): shorter row
      * chunks per wave, 4.1 -> 3.4 ms for one 50-iteration decode of the (64800, 32400) code */
-    if (d->T == 1 && !getenv("LDPC_TUNE_LINK_RPW")) d->link_rpw = 4;
+    if (d->T == 1 && !tune.link_rows) d->link_rpw = 4;
 
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&d->ev_begin));
@@ -765,12 +780,11 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
         if (cfg->pack_mode != LDPC_PACK_BYTES && cfg->K % 8)
             return fail(LDPC_ERR_UNSUPPORTED, "MS_FUSED packs whole bytes per frame only");
         /* flood_ldsp_kernel<.., CHAIN = false> (posteriors in LDS, 16-byte check records) wherever it fits
-         * with two workgroups per CU, else / with LDPC_TUNE_LDSP=0 the LDS-resident fused_flood_kernel */
-        const char *le = getenv("LDPC_TUNE_LDSP");
-        if (!(le && atoi(le) == 0)) {
+         * with two workgroups per CU, else / with LDPC_TUNE_OFF(LDPC_TUNE_LDSP) the LDS-resident fused_flood_kernel */
+        if (!ldpc::tune_forced_off(tune.ldsp)) {
             HIP_TRY(ldpc::ldsp_plan_create(&d->ldsp, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows, cfg->K,
-                                           cfg->max_batch, cfg->device, /*flood=*/2));
-            if (d->ldsp.eligible && ((le && atoi(le) != 0) || d->ldsp.lds_bytes <= 80 * 1024)) d->use_ldsp = true;
+                                           cfg->max_batch, cfg->device, tune, /*flood=*/2));
+            if (d->ldsp.eligible && (ldpc::tune_forced_on(tune.ldsp) || d->ldsp.lds_bytes <= 80 * 1024)) d->use_ldsp = true;
             else ldpc::ldsp_plan_destroy(&d->ldsp);
         }
         if (!d->use_ldsp) {
@@ -782,20 +796,18 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
         d->use_fused = true;
     } else if (cfg->algo == LDPC_ALGO_LAYERED) {
         /* short quasi-cyclic codes decode entirely in LDS, one launch (fused_kernels.hpp);
-         * LDPC_TUNE_FUSED=0 keeps the streaming kernels (same results, bit for bit) */
-        const char *fe = getenv("LDPC_TUNE_FUSED");
-        if (!(fe && atoi(fe) == 0) && (cfg->pack_mode == LDPC_PACK_BYTES || cfg->K % 8 == 0)) {
+         * LDPC_TUNE_OFF(LDPC_TUNE_FUSED) keeps the streaming kernels (same results, bit for bit) */
+        if (!ldpc::tune_forced_off(tune.fused) && (cfg->pack_mode == LDPC_PACK_BYTES || cfg->K % 8 == 0)) {
             HIP_TRY(ldpc::fused_plan_create(&d->fused, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows));
             d->use_fused = d->fused.eligible;
             /* layered_ldsp_kernel (posterior in LDS, 16-byte check records in cache) is the default for
              * every QC code it fits: larger codes cannot use the fully LDS-resident kernel at all, and on
              * short ones it is 1.2-2.9x faster (exact-width rows, bit-level sign algebra: 800 against 280 G
              * edge updates/s; circulants of <= 32 rows run several frames per wave in both).
-             * LDPC_TUNE_LDSP=0 forbids it (the LDS-resident kernel is then used where it applies). */
-            const char *le = getenv("LDPC_TUNE_LDSP");
-            if (le ? atoi(le) != 0 : true) {
+             * LDPC_TUNE_OFF(LDPC_TUNE_LDSP) forbids it (the LDS-resident kernel is then used where it applies). */
+            if (!ldpc::tune_forced_off(tune.ldsp)) {
                 HIP_TRY(ldpc::ldsp_plan_create(&d->ldsp, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows,
-                                               cfg->K, cfg->max_batch, cfg->device));
+                                               cfg->K, cfg->max_batch, cfg->device, tune));
                 if (d->ldsp.eligible) d->use_fused = d->use_ldsp = true;
             }
         }
@@ -813,14 +825,11 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
         /* Measured (tools/gpu_short.py): for the flooding schedules the streaming kernels win at
          * full work once the batch is large (HBM-bound, 1.3-1.9x), the fused kernels win on latency
          * and for small batches; crossover near max_batch * E = 2^23 edge-frames.
-         * LDPC_TUNE_FUSED=1 forces the fused kernels, =0 the streaming ones. */
+         * LDPC_TUNE_ON(LDPC_TUNE_FUSED) forces the fused kernels, LDPC_TUNE_OFF the streaming ones. */
         if (cfg->msg_dtype == LDPC_MSG_F32 && cfg->layer_rows > 0 && cfg->frames_per_lane == 0 &&
             (cfg->pack_mode == LDPC_PACK_BYTES || cfg->K % 8 == 0)) {
-            const char *fe = getenv("LDPC_TUNE_FUSED");
-            const char *le = getenv("LDPC_TUNE_LDSP");
-
             const bool small = (int64_t)cfg->max_batch * g->E <= (int64_t)1 << 23;
-            if (fe ? atoi(fe) != 0 : small) {
+            if (ldpc::tune_pick(tune.fused, small)) {
                 HIP_TRY(ldpc::fused_plan_create(&d->fused, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows));
                 d->use_fused = d->fused.eligible && (cfg->algo == LDPC_ALGO_MS || d->fused.eligible_sp);
             }
@@ -828,11 +837,11 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
              * Default wherever it fits with >= 2 workgroups per CU: 2-2.9x the LDS-resident kernel and the
              * streaming kernels on the 802.16e codes at any batch size ((2304, 1152): 9.9 / 4.0 / 2.9 Gbit/s
              * at 16 384 frames, 2.6 / 0.9 / 1.3 at full work), 2.4 / 2.0 / 1.7 / 1.2x the streaming kernels on
-             * BG1-profile codes at Z = 64 / 128 / 256 / 384.  LDPC_TUNE_LDSP=1 / 0 forces / forbids it. */
-            if (cfg->algo == LDPC_ALGO_MS && !(fe && atoi(fe) == 0) && !(le && atoi(le) == 0)) {
+             * BG1-profile codes at Z = 64 / 128 / 256 / 384.  LDPC_TUNE_ON / OFF(LDPC_TUNE_LDSP) forces / forbids it. */
+            if (cfg->algo == LDPC_ALGO_MS && !ldpc::tune_forced_off(tune.fused) && !ldpc::tune_forced_off(tune.ldsp)) {
                 HIP_TRY(ldpc::ldsp_plan_create(&d->ldsp, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows,
-                                               cfg->K, cfg->max_batch, cfg->device, /*flood=*/1));
-                if (d->ldsp.eligible && ((le && atoi(le) != 0) || d->ldsp.lds_bytes <= 80 * 1024))
+                                               cfg->K, cfg->max_batch, cfg->device, tune, /*flood=*/1));
+                if (d->ldsp.eligible && (ldpc::tune_forced_on(tune.ldsp) || d->ldsp.lds_bytes <= 80 * 1024))
                     d->use_fused = d->use_ldsp = true;
                 else
                     ldpc::ldsp_plan_destroy(&d->ldsp);
@@ -842,13 +851,14 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
             int rc = setup_flooding(d, g, TF);
             if (rc) return rc;
             /* tail compaction: with host polling on, the last <= 512 running frames of a batch of several
-             * tiles are finished by a small (8 x 64 frames) child decoder (LDPC_TUNE_COMPACT=0: off, n: threshold) */
-            if (const char *e = getenv("LDPC_TUNE_COMPACT")) d->compact_threshold = std::min(ldpc::kCompactCapacity, std::max(0, atoi(e)));
+             * tiles are finished by a small (8 x 64 frames) child decoder (cfg.tune_compact = -1: off, n: threshold) */
+            if (tune.compact) d->compact_threshold = tune.compact < 0 ? 0 : std::min(ldpc::kCompactCapacity, tune.compact);
             if (cfg->early_term && cfg->poll_interval > 0 && d->T > 1 && d->compact_threshold > 0 && !t_creating_child) {
                 ldpc_decoder_config cc = *cfg;
                 cc.max_batch = ldpc::kCompactCapacity;
                 cc.frames_per_lane = 1;
                 cc.layer_rows = 0;                 /* streaming kernels, same arithmetic */
+                cc.tune_compact = -1;
                 t_creating_child = true;
                 rc = ldpc_decoder_create(g, &cc, &d->child);
                 t_creating_child = false;
@@ -863,15 +873,66 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     return LDPC_OK;
 }
 
+/* Waits for the handle's OWN work: its two streams and, through the end-of-decode event, the
+ * caller's stream of the last ldpc_decode_device call -- not for the device, which other handles
+ * and the caller's other streams keep using. */
+static void wait_for_own_work(ldpc_decoder *d)
+{
+    if (d->child) wait_for_own_work(d->child);
+    (void)hipSetDevice(d->cfg.device);
+    if (d->have_last && d->ev_end) (void)hipEventSynchronize(d->ev_end);
+    if (d->stream) (void)hipStreamSynchronize(d->stream);
+    if (d->copy_stream) (void)hipStreamSynchronize(d->copy_stream);
+}
+
 int ldpc_decoder_destroy(ldpc_decoder *d)
 {
     if (!d) return LDPC_OK;
-    (void)hipSetDevice(d->cfg.device);
-    (void)hipDeviceSynchronize();
-    ldpc::layered_plan_destroy(&d->layered);
-    ldpc::fused_plan_destroy(&d->fused);
-    ldpc::ldsp_plan_destroy(&d->ldsp);
-    delete d;
+    if (d->shards.empty()) {
+        wait_for_own_work(d);
+        ldpc::layered_plan_destroy(&d->layered);
+        ldpc::fused_plan_destroy(&d->fused);
+        ldpc::ldsp_plan_destroy(&d->ldsp);
+    }
+    delete d;            /* a multi-device handle destroys its per-device decoders here */
+    return LDPC_OK;
+}
+
+int ldpc_shard_range(int64_t frames, int32_t part, int32_t parts, int32_t unit, int64_t *lo, int64_t *hi)
+{
+    if (!lo || !hi) return fail(LDPC_ERR_ARG, "lo/hi is NULL");
+    if (frames < 0 || parts <= 0 || part < 0 || part >= parts || unit <= 0)
+        return fail(LDPC_ERR_ARG, "shard_range(frames=%lld, part=%d, parts=%d, unit=%d)", (long long)frames, part, parts, unit);
+    const int64_t nu = (frames + unit - 1) / unit, base = nu / parts, rem = nu % parts;
+    const int64_t lo_u = part * base + std::min<int64_t>(part, rem);
+    const int64_t hi_u = lo_u + base + (part < rem ? 1 : 0);
+    *lo = std::min(lo_u * unit, frames);
+    *hi = std::min(hi_u * unit, frames);
+    return LDPC_OK;
+}
+
+int ldpc_decoder_create_multi(const ldpc_graph *g, const ldpc_decoder_config *cfg, const int32_t *devices,
+                              int32_t n_devices, ldpc_decoder **out)
+{
+    if (!out) return fail(LDPC_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!g || !cfg) return fail(LDPC_ERR_ARG, "graph/config is NULL");
+    if (!devices || n_devices <= 0 || n_devices > 64) return fail(LDPC_ERR_ARG, "devices[] must hold 1..64 ordinals");
+    ldpc_decoder *grp = new (std::nothrow) ldpc_decoder;
+    if (!grp) return fail(LDPC_ERR_NOMEM, "out of memory");
+    std::unique_ptr<ldpc_decoder> guard(grp);
+    for (int32_t i = 0; i < n_devices; ++i) {
+        ldpc_decoder_config c = *cfg;
+        c.device = devices[i];
+        ldpc_decoder *sh = nullptr;
+        const int rc = ldpc_decoder_create(g, &c, &sh);
+        if (rc) return rc;                       /* the guard destroys the shards made so far */
+        grp->shards.push_back(sh);
+    }
+    grp->cfg = *cfg;
+    grp->cfg.device = devices[0];
+    grp->M = g->M; grp->N = g->N; grp->E = g->E;
+    *out = guard.release();
     return LDPC_OK;
 }
 
@@ -879,6 +940,9 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
                        int64_t out_bytes, int32_t *iters_dev, void *stream)
 {
     if (!d) return fail(LDPC_ERR_ARG, "decoder is NULL");
+    if (!d->shards.empty())
+        return fail(LDPC_ERR_STATE, "a multi-device handle decodes host buffers only (ldpc_decode): device "
+                    "pointers belong to one device");
     if (frames < 0 || frames > d->cfg.max_batch)
         return fail(LDPC_ERR_ARG, "frames=%lld outside [0, max_batch=%d]", (long long)frames,
                     d->cfg.max_batch);
@@ -900,7 +964,8 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
         ldpc::FusedRun run{llr_dev, frames, out_dev, std::min(out_bytes, need), iters_dev, d->cfg.K,
                            d->cfg.max_iter, d->tap_iter, d->cfg.early_term, d->summary.p,
                            d->cfg.algo == LDPC_ALGO_MS_FUSED ? 1 : (d->cfg.algo == LDPC_ALGO_MS ? 2 : (d->cfg.algo == LDPC_ALGO_SP ? 3 : 0)),
-                           d->cfg.llr_scale};
+                           d->cfg.llr_scale, ldpc::tune_pick(d->tune.fused_loop, false) ? 1 : 0,
+                           ldpc::tune_pick(d->tune.fused_pack, true) ? 0 : 1};
         hipError_t e = span_begin(d, s, 2, 0, (int64_t)frames * (4 * d->N + d->cfg.K / 8));
         if (e == hipSuccess)
             e = d->use_ldsp ? ldpc::ldsp_run(&d->ldsp, run, s, &d->last_iterations)
@@ -932,15 +997,12 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
     return LDPC_OK;
 }
 
-int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t *out_host,
-                int64_t out_bytes, int32_t *iters)
+/* ldpc_decode on ONE device.  caller_pinned: the caller (the multi-device path) has already
+ * page-locked the whole input range. */
+static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t *out_host,
+                       int64_t out_bytes, int32_t *iters, bool caller_pinned)
 {
-    if (!d) return fail(LDPC_ERR_ARG, "decoder is NULL");
-    if (frames < 0) return fail(LDPC_ERR_ARG, "frames < 0");
-    if (frames == 0) return LDPC_OK;
-    if (!llr_host || !out_host) return fail(LDPC_ERR_ARG, "llr/out is NULL");
     const int64_t total = ldpc_out_bytes(d->cfg.K, frames, d->cfg.pack_mode);
-    if (out_bytes < 0) return fail(LDPC_ERR_ARG, "out_bytes < 0");
     HIP_TRY(hipSetDevice(d->cfg.device));
     const int64_t B = d->cfg.max_batch;
     if (d->cfg.pack_mode == LDPC_PACK_BITS && (d->cfg.K % 8) && frames > B)
@@ -967,23 +1029,35 @@ int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
     /* a finished group's bytes go from the pinned slot to the caller's buffers */
     auto drain = [&](ldpc_decoder::HostSlot &sl) -> int {
         if (!sl.busy) return LDPC_OK;
+        sl.busy = false;
         HIP_TRY(hipEventSynchronize(sl.all_done));
-
         if (sl.copy_bytes > 0) memcpy(out_host + sl.dst, sl.h_out, (size_t)sl.copy_bytes);
         if (iters) memcpy(iters + sl.off, sl.h_iters, (size_t)sl.n * sizeof(int32_t));
-        sl.busy = false;
         return LDPC_OK;
     };
-    std::vector<void *> pinned;
+    /* A copy from pageable memory waits for the device's other work (measured: 151 ms behind a
+     * 140 ms decode instead of 19 ms); page-locking the caller's input for the duration of the call
+     * makes every group's copy a true DMA that runs beside the previous group's kernels.  The whole
+     * range is registered ONCE (adjacent groups share pages) and released only after both streams
+     * have drained.  If the range cannot be registered (e.g. the caller has already page-locked it,
+     * or another call is decoding the same buffer) the copies simply stay pageable. */
+    bool own_pin = false;
+    if (nslots > 1 && !caller_pinned) {
+        if (hipHostRegister((void *)llr_host, (size_t)frames * d->N * sizeof(float), hipHostRegisterPortable) == hipSuccess)
+            own_pin = true;
+        else
+            (void)hipGetLastError();
+    }
     int rc = LDPC_OK;
-    const bool trace = getenv("LDPC_TRACE_HOST") != nullptr;
+#ifdef LDPC_TRACE_HOST
     const auto t_start = std::chrono::steady_clock::now();
-    auto stamp = [&](const char *what, int64_t kk) {
-        if (trace)
-            fprintf(stderr, "[ldpc_decode] %8.2f ms  group %lld  %s\n",
-                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(),
-                    (long long)kk, what);
-    };
+#define LDPC_STAMP(what, kk)                                                                             \
+    fprintf(stderr, "[ldpc_decode] %8.2f ms  group %lld  %s\n",                                          \
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), \
+            (long long)(kk), what)
+#else
+#define LDPC_STAMP(what, kk) ((void)0)
+#endif
     /* Coder::decode, MyLdpc.cpp:577-616: groups of batchSize frames, last one short.
      * stage_in(k): group k's channel values -> slot k % nslots, on the copy stream. */
     auto stage_in = [&](int64_t kk) -> int {
@@ -991,18 +1065,11 @@ int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
         const int r1 = drain(sl);                /* the slot's previous tenant (group kk - nslots) */
         if (r1) return r1;
         const int64_t off = kk * B, n = std::min(B, frames - off);
-        /* A copy from pageable memory waits for the device's other work (measured: 151 ms behind
-         * a 140 ms decode instead of 19 ms); pinning the caller's pages for the duration of the
-         * copy makes it a true DMA that runs beside the previous group's kernels. */
         const float *src = llr_host + (size_t)off * d->N;
-        if (nslots > 1 && hipHostRegister((void *)src, (size_t)n * d->N * sizeof(float), hipHostRegisterDefault) == hipSuccess)
-            pinned.push_back((void *)src);      /* unpinned after the last group: unregistering waits for the device */
-        else
-            (void)hipGetLastError();
         hipError_t e = hipMemcpyAsync(sl.llr.p, src, (size_t)n * d->N * sizeof(float), hipMemcpyHostToDevice, d->copy_stream);
         if (e == hipSuccess) e = hipEventRecord(sl.h2d_done, d->copy_stream);
         if (e != hipSuccess) return fail(LDPC_ERR_HIP, "host-to-device staging: %s", hipGetErrorString(e));
-        stamp("H2D enqueued", kk);
+        LDPC_STAMP("H2D enqueued", kk);
         return LDPC_OK;
     };
     rc = stage_in(0);
@@ -1015,7 +1082,7 @@ int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
         const int64_t chunk_bytes = ldpc_out_bytes(d->cfg.K, n, d->cfg.pack_mode);
         rc = ldpc_decode_device(d, sl.llr.p, n, sl.out.p, chunk_bytes, iters ? sl.iters.p : nullptr, d->stream);
         if (rc) break;
-        stamp("decode enqueued", k);
+        LDPC_STAMP("decode enqueued", k);
         /* byte offset of this group's first frame: (off*K)/8 in both packings */
         sl.off = off; sl.n = n;
         sl.dst = off * (int64_t)d->cfg.K / 8;
@@ -1028,18 +1095,101 @@ int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
         if (e != hipSuccess) { rc = fail(LDPC_ERR_HIP, "device-to-host staging: %s", hipGetErrorString(e)); break; }
         sl.busy = true;
     }
+#undef LDPC_STAMP
+    const std::string first_error = rc ? g_err : std::string();
     const int64_t k = ngroups;
     for (int i = 0; i < nslots; ++i) {          /* oldest first: slot (k % nslots) was filled earliest */
         const int r2 = drain(d->slot[(k + i) % nslots]);
         if (rc == LDPC_OK) rc = r2;
     }
-    for (void *p : pinned) (void)hipHostUnregister(p);
+    /* every exit path: nothing of this call is in flight any more when the pages are released */
+    (void)hipStreamSynchronize(d->copy_stream);
+    (void)hipStreamSynchronize(d->stream);
+    if (own_pin) (void)hipHostUnregister((void *)llr_host);
+    if (!first_error.empty()) g_err = first_error;
     return rc;
+}
+
+/* Shard boundaries that keep a multi-device result byte-identical to the single-device one: with
+ * K % 8 != 0 a frame's first byte is (frame*K)/8 with the division applied per launch group
+ * (MyLdpc.cpp:577-616 passes &srcCode[off*K/8]), so ranges must start where frame*K is a multiple
+ * of 8 -- and on a group boundary once the stream is longer than one group. */
+static int32_t shard_unit(const ldpc_decoder_config &cfg, int64_t frames)
+{
+    if (cfg.K % 8 == 0) return 1;
+    int64_t u = 8;
+    while (u > 1 && ((u / 2) * (int64_t)cfg.K) % 8 == 0) u /= 2;
+    if (frames > cfg.max_batch) {
+        int64_t a = u, b = cfg.max_batch;
+        while (b) { const int64_t t = a % b; a = b; b = t; }
+        u = u / a * cfg.max_batch;               /* lcm(u, max_batch) */
+    }
+    return (int32_t)std::min<int64_t>(u, 0x7fffffff);
+}
+
+int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t *out_host,
+                int64_t out_bytes, int32_t *iters)
+{
+    if (!d) return fail(LDPC_ERR_ARG, "decoder is NULL");
+    if (frames < 0) return fail(LDPC_ERR_ARG, "frames < 0");
+    if (frames == 0) return LDPC_OK;
+    if (!llr_host || !out_host) return fail(LDPC_ERR_ARG, "llr/out is NULL");
+    if (out_bytes < 0) return fail(LDPC_ERR_ARG, "out_bytes < 0");
+    if (d->shards.empty()) return decode_host(d, llr_host, frames, out_host, out_bytes, iters, false);
+
+    /* several devices: one host thread per device decodes a contiguous frame range */
+    const int n = (int)d->shards.size();
+    const int32_t unit = shard_unit(d->cfg, frames);
+    std::vector<int64_t> lo((size_t)n), hi((size_t)n);
+    int active = 0;
+    for (int i = 0; i < n; ++i) {
+        const int rc = ldpc_shard_range(frames, i, n, unit, &lo[i], &hi[i]);
+        if (rc) return rc;
+        active += hi[i] > lo[i];
+    }
+    bool pinned = false;
+    if (active > 1 || frames > d->cfg.max_batch) {
+        (void)hipSetDevice(d->shards[0]->cfg.device);
+        if (hipHostRegister((void *)llr_host, (size_t)frames * d->N * sizeof(float), hipHostRegisterPortable) == hipSuccess)
+            pinned = true;
+        else
+            (void)hipGetLastError();
+    }
+    std::vector<int> rcs((size_t)n, LDPC_OK);
+    std::vector<std::string> errs((size_t)n);
+    auto work = [&](int i) {
+        ldpc_decoder *sh = d->shards[i];
+        sh->have_last = false;
+        if (hi[i] <= lo[i]) return;
+        const int64_t base = lo[i] * (int64_t)d->cfg.K / 8;      /* exact: lo is a multiple of the unit */
+        const int64_t room = std::max<int64_t>(0, out_bytes - base);
+        rcs[i] = decode_host(sh, llr_host + (size_t)lo[i] * d->N, hi[i] - lo[i], out_host + base,
+                             std::min(room, ldpc_out_bytes(d->cfg.K, hi[i] - lo[i], d->cfg.pack_mode)),
+                             iters ? iters + lo[i] : nullptr, pinned);
+        if (rcs[i]) errs[i] = g_err;
+    };
+    std::vector<std::thread> threads;
+    for (int i = 1; i < n; ++i) threads.emplace_back(work, i);
+    work(0);
+    for (auto &t : threads) t.join();
+    if (pinned) (void)hipHostUnregister((void *)llr_host);
+    for (int i = 0; i < n; ++i)
+        if (rcs[i]) { g_err = errs[i]; return rcs[i]; }
+    d->have_last = true;
+    d->last_frames = frames;
+    return LDPC_OK;
 }
 
 int ldpc_decoder_set_timing(ldpc_decoder *d, int enable)
 {
     if (!d) return fail(LDPC_ERR_ARG, "decoder is NULL");
+    if (!d->shards.empty()) {
+        for (ldpc_decoder *sh : d->shards) {
+            const int rc = ldpc_decoder_set_timing(sh, enable);
+            if (rc) return rc;
+        }
+        return LDPC_OK;
+    }
     if (d->have_last) {   /* events of earlier calls may still be pending */
         HIP_TRY(hipSetDevice(d->cfg.device));
         HIP_TRY(hipEventSynchronize(d->ev_end));
@@ -1056,6 +1206,24 @@ int ldpc_decoder_stats(ldpc_decoder *d, ldpc_decode_stats *st)
     if (!d || !st) return fail(LDPC_ERR_ARG, "decoder/stats is NULL");
     memset(st, 0, sizeof *st);
     if (!d->have_last) return fail(LDPC_ERR_STATE, "no decode call to report on");
+    if (!d->shards.empty()) {
+        /* the devices ran side by side: counts add up, times and iteration numbers take the maximum.
+         * Each device reports its LAST launch group, as a single-device handle does. */
+        for (ldpc_decoder *sh : d->shards) {
+            if (!sh->have_last) continue;
+            ldpc_decode_stats one;
+            const int rc = ldpc_decoder_stats(sh, &one);
+            if (rc) return rc;
+            st->iterations_launched = std::max(st->iterations_launched, one.iterations_launched);
+            st->batch_time = std::max(st->batch_time, one.batch_time);
+            st->frames += one.frames;
+            st->frames_converged += one.frames_converged;
+            st->ms_total = std::max(st->ms_total, one.ms_total);
+            st->ms_check += one.ms_check; st->ms_var += one.ms_var; st->ms_other += one.ms_other;
+            st->launches_check += one.launches_check; st->launches_var += one.launches_var;
+        }
+        return LDPC_OK;
+    }
     HIP_TRY(hipSetDevice(d->cfg.device));
     HIP_TRY(hipEventSynchronize(d->ev_end));
     st->iterations_launched = d->last_iterations;
@@ -1079,6 +1247,7 @@ int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t ca
 {
     if (!d || !out || !count || capacity <= 0) return fail(LDPC_ERR_ARG, "bad arguments");
     *count = 0;
+    if (!d->shards.empty()) return ldpc_decoder_kernel_times(d->shards[0], out, capacity, count);
     if (!d->have_last) return fail(LDPC_ERR_STATE, "no decode call to report on");
     HIP_TRY(hipSetDevice(d->cfg.device));
     HIP_TRY(hipEventSynchronize(d->ev_end));
@@ -1111,6 +1280,7 @@ int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t ca
         ++out[k].launches;
         out[k].ms_total += ms;
         out[k].bytes_total += sp.bytes;
+        out[k].bytes_moved += sp.moved;
     }
     return LDPC_OK;
 }
@@ -1119,6 +1289,7 @@ int ldpc_decoder_set_tap(ldpc_decoder *d, int32_t iter)
 {
     if (!d) return fail(LDPC_ERR_ARG, "decoder is NULL");
     if (iter < 0) return fail(LDPC_ERR_ARG, "iter < 0");
+    if (!d->shards.empty()) return fail(LDPC_ERR_STATE, "debug taps need a single-device handle");
     d->tap_iter = iter;
     return LDPC_OK;
 }
@@ -1126,9 +1297,10 @@ int ldpc_decoder_set_tap(ldpc_decoder *d, int32_t iter)
 int ldpc_decoder_dump(ldpc_decoder *d, int32_t which, float *host_out, int64_t count)
 {
     if (!d || !host_out) return fail(LDPC_ERR_ARG, "decoder/host_out is NULL");
+    if (!d->shards.empty()) return fail(LDPC_ERR_STATE, "debug taps need a single-device handle");
     if (!d->have_last) return fail(LDPC_ERR_STATE, "no decode call to dump");
     HIP_TRY(hipSetDevice(d->cfg.device));
-    HIP_TRY(hipDeviceSynchronize());
+    wait_for_own_work(d);
     const int64_t frames = d->last_frames;
     const int V = d->V, F = d->F;
     const int tiles = (int)((frames + F - 1) / F);
@@ -1251,6 +1423,65 @@ int ldpc_count_errors_device(const uint8_t *out_dev, const uint8_t *ref_dev, int
     (void)hipFree(totals);
     if (e != hipSuccess) return fail(LDPC_ERR_HIP, "count_errors: %s", hipGetErrorString(e));
     for (int i = 0; i < 3; ++i) errors[i] = (int64_t)h[i];
+    return LDPC_OK;
+}
+
+/* ---- measurement aid: what this box's HBM sustains right now (a float4 copy: the figure the
+ *      microarchitecture guide quotes as achievable, 6.3 of 8.0 TB/s) ------------------------- */
+namespace {
+__global__ __launch_bounds__(256) void hbm_probe_copy_kernel(const ldpc::vf4 *__restrict__ src, ldpc::vf4 *__restrict__ dst, size_t n4)
+{
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i = (size_t)blockIdx.x * 256 * 4 + threadIdx.x; i < n4; i += stride) {
+        ldpc::vf4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + (size_t)k * 256 < n4) v[k] = src[i + (size_t)k * 256];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + (size_t)k * 256 < n4) dst[i + (size_t)k * 256] = v[k];
+    }
+}
+}  // namespace
+
+int ldpc_hbm_probe_device(int32_t device, int64_t bytes, int32_t reps, double *copy_gbs)
+{
+    if (!copy_gbs) return fail(LDPC_ERR_ARG, "copy_gbs is NULL");
+    *copy_gbs = 0.0;
+    if (bytes < (1 << 20) || bytes > ((int64_t)16 << 30) || reps <= 0 || reps > 1000)
+        return fail(LDPC_ERR_ARG, "probe: bytes in [1 MiB, 16 GiB], reps in [1, 1000]");
+    HIP_TRY(hipSetDevice(device));
+    const size_t n4 = (size_t)bytes / sizeof(ldpc::vf4);
+    ldpc::vf4 *src = nullptr, *dst = nullptr;
+    hipStream_t s = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t e = hipMalloc((void **)&src, n4 * sizeof(ldpc::vf4));
+    if (e == hipSuccess) e = hipMalloc((void **)&dst, n4 * sizeof(ldpc::vf4));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&a);
+    if (e == hipSuccess) e = hipEventCreate(&b);
+    if (e == hipSuccess) e = hipMemsetAsync(src, 0x3c, n4 * sizeof(ldpc::vf4), s);
+    float best_ms = 0.0f;
+    if (e == hipSuccess) {
+        const unsigned grid = (unsigned)std::min<size_t>((n4 + 1023) / 1024, 256 * 64);
+        hbm_probe_copy_kernel<<<grid, 256, 0, s>>>(src, dst, n4);        /* warm-up */
+        for (int r = 0; r < reps && e == hipSuccess; ++r) {
+            e = hipEventRecord(a, s);
+            hbm_probe_copy_kernel<<<grid, 256, 0, s>>>(src, dst, n4);
+            if (e == hipSuccess) e = hipEventRecord(b, s);
+            if (e == hipSuccess) e = hipEventSynchronize(b);
+            float ms = 0.0f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+            if (e == hipSuccess && (best_ms == 0.0f || ms < best_ms)) best_ms = ms;
+        }
+    }
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    if (s) (void)hipStreamDestroy(s);
+    if (src) (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+    if (e != hipSuccess) return fail(LDPC_ERR_HIP, "hbm probe: %s", hipGetErrorString(e));
+    if (best_ms > 0.0f) *copy_gbs = 2.0 * (double)(n4 * sizeof(ldpc::vf4)) / (best_ms * 1e-3) / 1e9;
     return LDPC_OK;
 }
 

@@ -1055,7 +1055,7 @@ inline LdspKernel flood_ldsp_kernel_for(int maxw, int kind)
 
 inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E, const std::vector<int32_t> &row_ptr,
                                    const std::vector<int32_t> &cols, int32_t z, int32_t K, int64_t max_batch, int device,
-                                   int flood = 0)
+                                   const Tune &tune, int flood = 0)
 {
     std::vector<int32_t> lp, bc, sh, e0;
     pl->eligible = false;
@@ -1066,10 +1066,8 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
     if (max_deg > kLdspMaxDeg) return hipSuccess;
     std::vector<int32_t> deg(nb, 0);
     for (int32_t b : bc) ++deg[b];
-    const char *ee = getenv("LDPC_TUNE_LDSP_EXT");
-    const char *pe0 = getenv("LDPC_TUNE_LDSP_PACK");
-    const bool will_pack = z <= 32 && !(pe0 && atoi(pe0) == 0);
-    const bool allow_ext = !(ee && atoi(ee) == 0) && !(flood && will_pack);   /* the packed flooding kernel keeps every column in LDS */
+    const bool will_pack = z <= 32 && !tune_forced_off(tune.ldsp_pack);
+    const bool allow_ext = !tune_forced_off(tune.ldsp_ext) && !(flood && will_pack);   /* the packed flooding kernel keeps every column in LDS */
     std::vector<int32_t> slot(nb, 0), hdr((size_t)layers * 4, 0), pack((size_t)layers * 2 * kLdspMaxDeg, 0);
     std::vector<char> external(nb, 0);
     int ext_cols = 0;
@@ -1092,12 +1090,9 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
         }
     }
     int mw = (z + 63) / 64;
-    if (const char *t = getenv("LDPC_TUNE_LDSP_WAVES")) mw = std::min(16, std::max(mw, atoi(t)));   /* idle waves appended */
+    if (tune.ldsp_waves) mw = std::min(16, std::max(mw, tune.ldsp_waves));   /* idle waves appended */
     int frames_per_wg = 1;
-    {
-        const char *pe = getenv("LDPC_TUNE_LDSP_PACK");
-        if (mw == 1 && z <= 32 && !(pe && atoi(pe) == 0)) frames_per_wg = 64 / z;
-    }
+    if (mw == 1 && will_pack) frames_per_wg = 64 / z;
     const size_t frame_bytes = ((((size_t)lds_cols * z + 1) & ~(size_t)1)) * sizeof(float) * (flood ? 2 : 1);   /* flooding: old and new image */
     while (frames_per_wg > 1 && frames_per_wg * frame_bytes + (size_t)layers * sizeof(uint64_t) + 8 > 60 * 1024) --frames_per_wg;
     const size_t lds_bytes = frames_per_wg * frame_bytes + (size_t)layers * mw * sizeof(uint64_t) + 8;
@@ -1126,10 +1121,10 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, pl->block, lds_bytes))) return e;
     if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device))) return e;
     if (per_cu < 1 || cus < 1) return hipErrorInvalidValue;
-    if (const char *t = getenv("LDPC_TUNE_LDSP_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(t)));
+    if (tune.ldsp_per_cu) per_cu = std::max(1, std::min(per_cu, tune.ldsp_per_cu));
     pl->per_cu = per_cu;
     pl->grid = (int32_t)std::min<int64_t>((std::max<int64_t>(max_batch, 1) + pl->wg_frames - 1) / pl->wg_frames, (int64_t)per_cu * cus);
-    if (const char *t = getenv("LDPC_TUNE_LDSP_GRID")) pl->grid = std::max(1, std::min(pl->grid, atoi(t)));
+    if (tune.ldsp_grid) pl->grid = std::max(1, std::min(pl->grid, tune.ldsp_grid));
     if ((e = hipMalloc((void **)&pl->recs, (size_t)pl->grid * pl->wg_frames * M * sizeof(uint4)))) return e;
     if ((e = hipMalloc((void **)&pl->zf, (size_t)pl->grid * pl->wg_frames * M * sizeof(uint32_t)))) return e;
     pl->eligible = true;

@@ -1,0 +1,63 @@
+/*
+ * tune.hpp -- the tuning fields of ldpc_decoder_config (include/ldpc_hip.h) unpacked once per
+ * decoder.  Kernel selection and launch shapes only: results never depend on them.  The library
+ * reads no environment variables; harnesses translate their own switches into these fields.
+ */
+#pragma once
+
+#include "../../include/ldpc_hip.h"
+
+namespace ldpc {
+
+struct Tune {
+    /* tri-state: 0 automatic, 1 forced on, 2 forced off */
+    int fused = 0, ldsp = 0, ldsp_ext = 0, ldsp_pack = 0, link_narrow = 0, check_wide = 0, syn_xcd = 0,
+        fused_pack = 0, fused_loop = 0, device_tail = 0;
+    int rows_per_wave = 0, cols_per_wave = 0;
+    int link_rows = 0;          /* 0 automatic, -1 fusion off */
+    int compact = 0;            /* 0 automatic, -1 off */
+    int ldsp_grid = 0, ldsp_per_cu = 0, ldsp_waves = 0;
+};
+
+inline Tune tune_from_config(const ldpc_decoder_config &c)
+{
+    Tune t;
+    auto f = [&](int field) { return (c.tune_flags >> field) & 3; };
+    t.fused = f(LDPC_TUNE_FUSED);
+    t.ldsp = f(LDPC_TUNE_LDSP);
+    t.ldsp_ext = f(LDPC_TUNE_LDSP_EXT);
+    t.ldsp_pack = f(LDPC_TUNE_LDSP_PACK);
+    t.link_narrow = f(LDPC_TUNE_LINK_NARROW);
+    t.check_wide = f(LDPC_TUNE_CHECK_WIDE);
+    t.syn_xcd = f(LDPC_TUNE_SYN_XCD);
+    t.fused_pack = f(LDPC_TUNE_FUSED_PACK);
+    t.fused_loop = f(LDPC_TUNE_FUSED_LOOP);
+    t.device_tail = f(LDPC_TUNE_DEVICE_TAIL);
+    t.rows_per_wave = c.tune_rows_per_wave;
+    t.cols_per_wave = c.tune_cols_per_wave;
+    t.link_rows = c.tune_link_rows;
+    t.compact = c.tune_compact;
+    t.ldsp_grid = c.tune_ldsp_grid;
+    t.ldsp_per_cu = c.tune_ldsp_shape & 255;
+    t.ldsp_waves = (c.tune_ldsp_shape >> 8) & 255;
+    return t;
+}
+
+/* the choice a tri-state field makes when the automatic answer is `dflt` */
+inline bool tune_pick(int tri, bool dflt) { return tri == 1 ? true : (tri == 2 ? false : dflt); }
+inline bool tune_forced_on(int tri) { return tri == 1; }
+inline bool tune_forced_off(int tri) { return tri == 2; }
+
+/* field 3 (both bits) is not a value */
+inline bool tune_valid(const ldpc_decoder_config &c)
+{
+    for (int field = 0; field <= LDPC_TUNE_DEVICE_TAIL; field += 2)
+        if (((c.tune_flags >> field) & 3) == 3) return false;
+    if (c.tune_flags >> (LDPC_TUNE_DEVICE_TAIL + 2)) return false;
+    return c.tune_rows_per_wave >= 0 && c.tune_rows_per_wave <= 4096 && c.tune_cols_per_wave >= 0 &&
+           c.tune_cols_per_wave <= 4096 && c.tune_link_rows >= -1 && c.tune_link_rows <= 4096 &&
+           c.tune_compact >= -1 && c.tune_ldsp_grid >= 0 && c.tune_ldsp_shape >= 0 && c.tune_ldsp_shape < 65536 &&
+           c.reserved == 0;
+}
+
+}  // namespace ldpc

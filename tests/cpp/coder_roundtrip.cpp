@@ -1,14 +1,20 @@
 // Round-trip harness in the shape of the reference's only test, Test.cpp:15-118:
 //   payload 'a'+i%26 -> encode -> AWGN (sd = 10^(-snr/20)) -> decode -> ErrNum / ThroughPut.
 // Usage: coder_roundtrip <rate 0..5> <N> <srcBytes> <batch> <snr_dB> <SP|MS|CPU|TDMP|TDMPCL|MSCL|ENC> [seed]
+//                        [--devices 0,0,...] [--dump <prefix>] [--iters n]
 // ENC: encoder only (no GPU): checks H c = 0 for every frame and prints "ParityFail=<n>".
-// Prints the reference's fields (sd=, Time=, <MODE>:<seconds>, ErrNum=, ThroughPut=).
+// --devices: Coder::setDevices (one Coder over several HIP devices; an ordinal may repeat).
+// --dump: writes <prefix>.prior (encoded bytes), <prefix>.post (channel floats), <prefix>.out (decoded
+//         bytes) so that a test can run the oracle on exactly these inputs.
+// Prints NonZeros= and the reference's fields (sd=, Time=, <MODE>:<seconds>, ErrNum=, ThroughPut=).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <iostream>
+#include <string>
+#include <vector>
 
 #include "MyLdpc.h"
 using namespace std;
@@ -24,9 +30,26 @@ int main(int argc, char **argv)
     const int batch = atoi(argv[4]);
     const float snr = (float)atof(argv[5]);
     const char *mode = argv[6];
-    srand(argc > 7 ? atoi(argv[7]) : 1);
+    srand(argc > 7 && argv[7][0] != '-' ? atoi(argv[7]) : 1);
+    std::vector<int> devices;
+    std::string dump;
+    int iters = 0;
+    for (int i = 7; i + 1 < argc; ++i) {
+        if (!strcmp(argv[i], "--devices"))
+            for (char *tok = strtok(argv[i + 1], ","); tok; tok = strtok(nullptr, ",")) devices.push_back(atoi(tok));
+        else if (!strcmp(argv[i], "--dump")) dump = argv[i + 1];
+        else if (!strcmp(argv[i], "--iters")) iters = atoi(argv[i + 1]);
+    }
+    auto save = [&](const char *ext, const void *p, size_t n) {
+        if (dump.empty()) return;
+        FILE *f = fopen((dump + ext).c_str(), "wb");
+        if (f) { fwrite(p, 1, n, f); fclose(f); }
+    };
 
     Coder coder(ldpcK, ldpcN, rate);
+    cout << "NonZeros=" << coder.getNonZeros() << endl;
+    if (iters > 0) coder.setMaxIterations(iters);
+    if (!devices.empty()) coder.setDevices(devices.data(), (int)devices.size());
     char *srcCode = (char *)malloc(srcLength);
     char *priorCode = (char *)malloc(coder.getPriorCodeLength(srcLength));
     float *postCode = (float *)malloc(sizeof(float) * coder.getPostCodeLength(srcLength));
@@ -46,17 +69,19 @@ int main(int argc, char **argv)
                 for (int p = rr[m]; p < rr[m + 1]; ++p) par ^= (cw[cc[p] / 8] >> (cc[p] % 8)) & 1;
                 bad += par;
             }
-            if (memcmp(cw, srcCode + (size_t)f * (ldpcK / 8),
-                       (size_t)std::min(ldpcK / 8, srcLength - f * (ldpcK / 8))))
+            const long long at = (long long)f * ldpcK / 8;          // MyLdpc.cpp:559: offset * ldpcK / 8
+            if (at < srcLength && memcmp(cw, srcCode + at, (size_t)std::min<long long>(ldpcK / 8, srcLength - at)))
                 ++bad;   // systematic part must be the payload
         }
         cout << "ParityFail=" << bad << endl;
+        save(".prior", priorCode, (size_t)coder.getPriorCodeLength(srcLength));
         if (!strcmp(mode, "ENC")) return bad ? 1 : 0;
     }
     if (coder.forDecoder(batch)) { cout << "forDecoder failed: " << coder.lastError() << endl; return 1; }
     const float sd = 1 / (pow(10, snr / 20));                          // Test.cpp:56
     cout << "sd=" << sd << endl;
     coder.test(priorCode, postCode, coder.getPriorCodeLength(srcLength), sd);
+    save(".post", postCode, sizeof(float) * (size_t)coder.getPostCodeLength(srcLength));
 
     enum decodeType t;
     if (!strcmp(mode, "SP")) t = DecodeSP;
@@ -77,6 +102,7 @@ int main(int argc, char **argv)
     int errNum = 0;
     for (int i = 0; i < srcLength; ++i)
         if (srcCode[i] != newSrcCode[i]) ++errNum;                     // Test.cpp:105-109
+    save(".out", newSrcCode, (size_t)srcLength);
     cout << "ErrNum=" << errNum << endl;
     cout << "ThroughPut=" << srcLength / decodeTime << endl;
     free(srcCode); free(priorCode); free(postCode); free(newSrcCode);

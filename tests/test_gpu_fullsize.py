@@ -1,6 +1,10 @@
 """BASELINE.json's full-size code on the GPU: DVB-S2-profile (64800, 32400).
 Bit-exact against the oracle on sampled frames, plus size-independent properties
 (codeword symmetry, noiseless idempotence, all-zero decode)."""
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 import pytest
 
@@ -110,7 +114,7 @@ def test_high_rate_check_degree_30(built):
         dec.close()
 
 
-def test_layered_bg1_profile_z384(built, monkeypatch):
+def test_layered_bg1_profile_z384(built):
     """configs[3] shape: BG1-profile QC code, Z = 384 (N = 26112, E = 121344), layered
     min-sum with 384-row layers.  Two frames against the oracle bit for bit, and the
     codeword symmetry over the whole batch."""
@@ -144,8 +148,7 @@ def test_layered_bg1_profile_z384(built, monkeypatch):
     dec.close()
     # the default above is layered_ldsp_kernel (posterior in LDS); the one-launch-per-layer
     # streaming kernels must give the same bits, iteration counts and messages for all 70 frames
-    monkeypatch.setenv("LDPC_TUNE_LDSP", "0")
-    dec = L.Decoder(g, Kb, max_batch=B, algo="layered", max_iter=20, layer_rows=Z)
+    dec = L.Decoder(g, Kb, max_batch=B, algo="layered", max_iter=20, layer_rows=Z, tune={"ldsp": False})
     out1, it1 = dec.decode(y0)
     assert np.array_equal(out1, out0) and np.array_equal(it1, it0)
     dec.set_tap(2)
@@ -154,18 +157,13 @@ def test_layered_bg1_profile_z384(built, monkeypatch):
     assert np.array_equal(dec.dump(0, B)[run], r_ldsp[run]) and np.array_equal(dec.dump(2, B)[run], p_ldsp[run])
     dec.close()
     # fewer persistent workgroups than frames
-    monkeypatch.setenv("LDPC_TUNE_LDSP", "1")
-    monkeypatch.setenv("LDPC_TUNE_LDSP_GRID", "16")
-    dec = L.Decoder(g, Kb, max_batch=B, algo="layered", max_iter=20, layer_rows=Z)
+    dec = L.Decoder(g, Kb, max_batch=B, algo="layered", max_iter=20, layer_rows=Z, tune={"ldsp": True, "ldsp_grid": 16})
     out2, it2 = dec.decode(y0)
     assert np.array_equal(out2, out0) and np.array_equal(it2, it0)
     dec.close()
     # all 68 block columns in LDS (104 KB of dynamic LDS, one workgroup per CU), alive together with a
     # decoder of a small code that uses the same kernel with 10 KB
-    monkeypatch.delenv("LDPC_TUNE_LDSP_GRID")
-    monkeypatch.setenv("LDPC_TUNE_LDSP_EXT", "0")
-    big = L.Decoder(g, Kb, max_batch=B, algo="layered", max_iter=20, layer_rows=Z)
-    monkeypatch.delenv("LDPC_TUNE_LDSP_EXT")
+    big = L.Decoder(g, Kb, max_batch=B, algo="layered", max_iter=20, layer_rows=Z, tune={"ldsp": True, "ldsp_ext": False})
     zs = 96
     rs, cs = codes.qc_edges(codes.nr_bg1_profile_base(Z=zs), zs)
     gs = L.Graph(rs, cs, 46 * zs, 68 * zs)
@@ -227,3 +225,149 @@ def test_tail_compaction_at_full_size(built, code):
     assert st["frames_converged"] == int((iters < 25).sum())
     assert st["iterations_launched"] == int(iters.max())
     dec.close()
+
+
+def test_bg1_layered_at_its_full_batch_of_8192(built):
+    """BASELINE.json configs[3] at its real size: BG1-profile Z = 384 (N = 26112, E = 121344), layered
+    min-sum, batch 8192, device buffers.  The persistent grid of the record kernel (768 workgroups)
+    wraps over the frames ~11 times.  Checked: the codeword symmetry decode(noise on c) =
+    decode(noise on 0) XOR c with equal iteration counts over the WHOLE batch (16 distinct codewords,
+    8192 distinct noise frames), and frames 0, 767, 768, 4100 and 8191 bit for bit against the oracle."""
+    import torch
+    Z = 384
+    base = codes.nr_bg1_profile_base(Z=Z)
+    rows, cols = codes.qc_edges(base, Z)
+    Nb, Kb, Mb = 68 * Z, 22 * Z, 46 * Z
+    g = L.Graph(rows, cols, Mb, Nb)
+    og = oracle.Graph(rows, cols, Mb, Nb, Kb)
+    B = 8192
+    rng = np.random.default_rng(17)
+    cws = np.stack([codes.nr_bg1_profile_encode(base, Z, rng.integers(0, 2, Kb).astype(np.uint8)) for _ in range(16)])
+    which = rng.integers(0, 16, B)
+    bits = torch.from_numpy(cws[which]).cuda()                               # [B, N] code bits
+    # 7680 frames that converge within a few iterations, then 512 that never do
+    y0 = torch.empty((B, Nb), dtype=torch.float32, device="cuda")            # noise on the all-zero word
+    yc = torch.empty((B, Nb), dtype=torch.float32, device="cuda")            # the same noise on the codewords
+    for lo, hi, sd in ((0, 7680, 0.9), (7680, B, 1.2)):
+        channel.awgn_device(Nb, lo, hi - lo, sd, seed=63, out=y0[lo:hi])
+        channel.awgn_device(Nb, lo, hi - lo, sd, seed=63, codewords=bits[lo:hi], out=yc[lo:hi])
+    dec = L.Decoder(g, Kb, max_batch=B, algo="layered", max_iter=20, layer_rows=Z)
+    nb = L.out_bytes(Kb, B)
+    outs, its = [], []
+    for y in (y0, yc):
+        out = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        it = torch.empty(B, dtype=torch.int32, device="cuda")
+        dec.decode_device(y.data_ptr(), B, out.data_ptr(), nb, it.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+        its.append(it.cpu().numpy())
+    st = dec.stats()
+    b0 = channel.unpack_bits(outs[0], Kb, B)
+    bc = channel.unpack_bits(outs[1], Kb, B)
+    assert np.array_equal(bc, b0 ^ cws[which][:, :Kb])
+    assert np.array_equal(its[0], its[1])
+    assert (its[0][:7680] < 20).mean() > 0.99 and (its[0][7680:] == 20).mean() > 0.99     # both kinds of frames
+    assert st["frames"] == B and st["batch_time"] == 20
+    pick = [0, 767, 768, 4100, 7700, 8191]
+    o = oracle.decode(og, y0[pick].cpu().numpy(), "layered", max_iter=20, layer_rows=Z)
+    kb = Kb // 8
+    for i, f in enumerate(pick):
+        assert o["undefined"][i] == 0
+        assert np.array_equal(outs[0][f * kb:(f + 1) * kb], o["out"][i * kb:(i + 1) * kb]), f
+        assert its[0][f] == o["iters"][i], f
+    dec.close()
+
+
+def test_rate_910_fp16_early_termination_at_its_full_batch_of_4096(built):
+    """BASELINE.json configs[4] at its real size: DVB-S2-profile (64800, 58320), fp16 message storage,
+    early termination with host polling and tail compaction, batch 4096.  Iteration counts of ALL
+    frames and all bytes equal an unpolled, uncompacted run; 264 frames (the first tile + 8 scattered
+    ones, the last included) equal the oracle's fp16-message min-sum (frames decoded in threads)."""
+    N2, K2 = 64800, 58320
+    rows, cols = codes.dvbs2_profile_edges(N2, K2)
+    g = L.Graph(rows, cols, N2 - K2, N2)
+    og = oracle.Graph(rows, cols, N2 - K2, N2, K2)
+    B = 4096
+    y = channel.awgn_device(N2, 0, B, 0.34, seed=64).cpu().numpy()
+    hard_idx = [5, 1300, 2222, 4095]
+    y[hard_idx] = channel.awgn_device(N2, 9000, 4, 0.46, seed=65).cpu().numpy()      # stragglers -> the child
+    ref = L.Decoder(g, K2, max_batch=B, algo="ms", max_iter=50, msg_dtype="f16", poll_interval=0,
+                    tune={"compact": -1, "device_tail": False})
+    out_ref, it_ref = ref.decode(y)
+    st_ref = ref.stats()
+    ref.close()
+    dec = L.Decoder(g, K2, max_batch=B, algo="ms", max_iter=50, msg_dtype="f16", poll_interval=2)
+    out, iters = dec.decode(y)
+    st = dec.stats()
+    dec.close()
+    assert np.array_equal(iters, it_ref) and np.array_equal(out, out_ref)
+    assert iters[hard_idx].min() > np.delete(iters, hard_idx).max()                    # the premise: they ran on alone
+    assert st["frames_converged"] == st_ref["frames_converged"] >= int((iters < 50).sum())
+    pick = np.r_[np.arange(256), [1300, 2047, 2048, 2222, 3000, 3839, 3840, 4095]]
+    kb = K2 // 8
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
+        res = list(ex.map(lambda f: oracle.decode(og, y[f:f + 1], "ms", max_iter=50, msg_f16=True), pick))
+    for f, o in zip(pick, res):
+        assert np.array_equal(out[f * kb:(f + 1) * kb], o["out"]), f
+        assert iters[f] == o["iters"][0], f
+
+
+def test_cpp_coder_at_the_reference_constructible_full_size(built, tmp_path):
+    """The largest code the reference's own constructor can make at this length:
+    Coder(32400, 64800, rate_1_2) -- z = 2700, E = 205200 (tests/golden/graph_facts.npz) -- through
+    the C++ class end to end like Test.cpp: 256 frames, structured encoder at N = 64800, Coder::test
+    channel, SP / MS / CPU decode.  ParityFail = 0, ErrNum = 0, and the MS and CPU bytes equal the
+    oracle's decode of the very same postCode floats (32 frames)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "coder_roundtrip")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "coder_roundtrip.cpp"), "-o", exe,
+                           "-L" + os.path.join(root, "myldpccppapi_amd"), "-lmyldpc", "-lldpc_hip",
+                           "-Wl,-rpath," + os.path.join(root, "myldpccppapi_amd")])
+    frames, kb = 256, 32400 // 8
+    src_len = frames * kb
+    rows, cols = codes.wimax_edges(codes.RATE_1_2, 64800)
+    assert len(rows) == 205200
+    og = oracle.Graph(rows, cols, 32400, 64800, 32400)
+    for mode, snr in (("SP", "6"), ("MS", "3"), ("CPU", "3")):
+        pre = str(tmp_path / mode)
+        out = subprocess.run([exe, "0", "64800", str(src_len), "256", snr, mode, "3", "--dump", pre],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        fields = dict(l.split("=", 1) for l in out.stdout.split() if "=" in l)
+        assert fields["NonZeros"] == "205200" and fields["ParityFail"] == "0" and fields["ErrNum"] == "0", out.stdout
+        if mode == "SP":
+            continue
+        post = np.fromfile(pre + ".post", np.float32).reshape(frames, 64800)
+        got = np.fromfile(pre + ".out", np.uint8)
+        with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
+            res = list(ex.map(lambda f: oracle.decode(og, post[f:f + 1], "ms", max_iter=40)["out"], range(32)))
+        assert np.array_equal(got[:32 * kb], np.concatenate(res)), mode
+        assert int(fields["Time"]) < 40
+
+
+def test_cpp_coder_round_trip_with_frames_not_byte_aligned(built, tmp_path):
+    """Coder(324, 648, rate_1_2): K % 8 = 4.  encode() reads frame f at source byte (f*K)/8 and
+    decode() writes it there (MyLdpc.cpp:556-564, decodeCL.c:191-192), so over 5 frames the source
+    bytes 80 and 161 belong to no frame: a noiseless-ish round trip returns the payload except for
+    exactly those bytes (zero) -- the reference's behaviour, kept."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "coder_roundtrip")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "coder_roundtrip.cpp"), "-o", exe,
+                           "-L" + os.path.join(root, "myldpccppapi_amd"), "-lmyldpc", "-lldpc_hip",
+                           "-Wl,-rpath," + os.path.join(root, "myldpccppapi_amd")])
+    src_len = 167
+    src = np.array([ord("a") + i % 26 for i in range(src_len)], np.uint8)
+    for mode in ("SP", "MS", "TDMPCL"):
+        for batch in ("8", "2"):
+            pre = str(tmp_path / ("k4_%s_%s" % (mode, batch)))
+            out = subprocess.run([exe, "0", "648", str(src_len), batch, "9", mode, "4", "--dump", pre],
+                                 capture_output=True, text=True)
+            assert out.returncode == 0 and "ParityFail=0" in out.stdout, out.stdout + out.stderr
+            got = np.fromfile(pre + ".out", np.uint8)
+            bad = np.nonzero(got != src)[0]
+            # frames end at a 4-bit boundary: the last half byte of each frame's K bits is not packed (toChar
+            # writes K/8 whole bytes), so the only differences are the two orphan bytes
+            assert bad.tolist() == [80, 161], (mode, batch, bad)
+            assert got[80] == 0 and got[161] == 0

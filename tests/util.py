@@ -25,6 +25,25 @@ def wimax_oracle_graph(rate, N):
     return oracle.Graph(rows, cols, M, N, K), rows, cols, K, M, z
 
 
+def kernel_choice(mode, grid=0):
+    """Tuning dict for L.Decoder(tune=...): "1" = LDS-resident fused kernels, "ldsp" = record
+    kernels (posteriors in LDS, check records in cache), "0" = HBM-streaming kernels."""
+    t = {"fused": mode != "0", "ldsp": mode == "ldsp"}
+    if grid:
+        t["ldsp_grid"] = grid
+    return t
+
+
+def converged_frames(rows, cols, M, hard):
+    """Per frame: are all parity checks of the final hard bits even?  (The reference's flags == 0,
+    decodeCL.c:88-108; a frame can end clean exactly at the last iteration, so `iters < max_iter`
+    is not the same thing.)"""
+    hard = np.asarray(hard, np.uint8)
+    syn = np.zeros((hard.shape[0], M), np.int64)
+    np.add.at(syn, (slice(None), np.asarray(rows)), hard[:, np.asarray(cols)].astype(np.int64))
+    return ~(syn & 1).any(axis=1)
+
+
 def first_clean_iters(flags_or_iters):
     return np.asarray(flags_or_iters)
 

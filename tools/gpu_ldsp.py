@@ -23,7 +23,7 @@ ref = None
 for mode in modes:
     os.environ["LDPC_TUNE_LDSP"] = "1" if mode == "ldsp" else "0"
     os.environ["LDPC_TUNE_FUSED"] = "1" if mode == "ldsp" else "0"
-    dec = L.Decoder(g, K, max_batch=B, algo=algo, layer_rows=Z, max_iter=iters, early_term=early)
+    dec = L.Decoder(g, K, max_batch=B, algo=algo, layer_rows=Z, max_iter=iters, early_term=early, tune=L.capi.tune_from_env())
     for _ in range(2):
         dec.decode_device(y.data_ptr(), B, out.data_ptr(), out.numel(), it.data_ptr(), None)
     torch.cuda.synchronize()

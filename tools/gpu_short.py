@@ -18,7 +18,7 @@ it = torch.empty(B, dtype=torch.int32, device="cuda")
 for fused in ("1", "ldsp", "0") if algo in ("layered", "ms") else (("1", "ldsp") if algo == "ms_fused" else ("1", "0")):
     os.environ["LDPC_TUNE_FUSED"] = "1" if fused == "ldsp" else fused
     os.environ["LDPC_TUNE_LDSP"] = "1" if fused == "ldsp" else "0"
-    dec = L.Decoder(g, K, max_batch=B, algo=algo, layer_rows=z, max_iter=40, poll_interval=0)
+    dec = L.Decoder(g, K, max_batch=B, algo=algo, layer_rows=z, max_iter=40, poll_interval=0, tune=L.capi.tune_from_env())
     for _ in range(2):
         dec.decode_device(y.data_ptr(), B, out.data_ptr(), out.numel(), it.data_ptr(), None)
     torch.cuda.synchronize()

@@ -55,7 +55,7 @@ for case in range(cases):
             os.environ.update(env)
             os.environ["LDPC_TUNE_LDSP_GRID"] = str(int(rng.integers(1, 9)))
             try:
-                dec = L.Decoder(g, K, max_batch=B, algo=algo, layer_rows=z, max_iter=iters)
+                dec = L.Decoder(g, K, max_batch=B, algo=algo, layer_rows=z, max_iter=iters, tune=L.capi.tune_from_env())
             except L.LdpcError as e:
                 if algo == "ms_fused":
                     continue            # not every structure fits the one-launch kernels
@@ -89,7 +89,8 @@ for case in range(max(4, cases // 6)):
     os.environ["LDPC_TUNE_LDSP"] = "0"
     os.environ["LDPC_TUNE_COMPACT"] = str(int(rng.choice([512, 512, 64, 9])))
     dec = L.Decoder(g, K, max_batch=B, algo=algo, max_iter=iters, poll_interval=int(rng.integers(1, 4)),
-                    frames_per_lane=int(rng.choice([1, 2, 4])), msg_dtype="f16" if f16 else "f32")
+                    frames_per_lane=int(rng.choice([1, 2, 4])), msg_dtype="f16" if f16 else "f32",
+                    tune=L.capi.tune_from_env())
     out, it = dec.decode(y)
     good = np.array_equal(out, want["out"]) and np.array_equal(it, want["iters"])
     dec.close()

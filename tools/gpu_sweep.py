@@ -12,7 +12,7 @@ reps = int(sys.argv[6]) if len(sys.argv) > 6 else 2
 N, K = 64800, 32400
 rows, cols = codes.dvbs2_profile_edges(N, K)
 g = L.Graph(rows, cols, N - K, N)
-dec = L.Decoder(g, K, max_batch=B, algo=algo, max_iter=iters, frames_per_lane=V, early_term=bool(et))
+dec = L.Decoder(g, K, max_batch=B, algo=algo, max_iter=iters, frames_per_lane=V, early_term=bool(et), tune=L.capi.tune_from_env())
 torch.manual_seed(1)
 y = (1.0 + 0.95 * torch.randn(B, N, device="cuda", dtype=torch.float32))
 out = torch.empty(L.out_bytes(K, B), dtype=torch.uint8, device="cuda")
