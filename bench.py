@@ -51,8 +51,8 @@ EXTRA_CONFIGS = {
                         batch=8192, iters=20, sigma=1.1, algo="layered", msg="f32", early=True, poll=0),
     "dvbs2_910_f16": dict(desc="DVB-S2-profile (64800,58320) rate-9/10 (E=194399, check degree 30), batch 4096, "
                                "flooding min-sum with fp16 messages, early termination (syndrome) on, "
-                               "max 50 iterations, sigma=0.30",
-                          batch=4096, iters=50, sigma=0.30, algo="ms", msg="f16", early=True, poll=2),
+                               "max 50 iterations, sigma=0.43",
+                          batch=4096, iters=50, sigma=0.43, algo="ms", msg="f16", early=True, poll=2),
 }
 
 

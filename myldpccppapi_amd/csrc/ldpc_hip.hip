@@ -221,6 +221,7 @@ struct ldpc_decoder {
         DevBuf<int32_t> iters;
         uint8_t *h_out = nullptr;       /* pinned: D2H completes without blocking the host */
         int32_t *h_iters = nullptr;
+        uint8_t *h_head = nullptr;      /* pinned page: a group's bytes before its first page boundary */
         hipEvent_t h2d_done = nullptr, all_done = nullptr;
         bool busy = false;
         int64_t off = 0, n = 0, dst = 0, copy_bytes = 0;
@@ -264,6 +265,7 @@ struct ldpc_decoder {
         for (auto &sl : slot) {
             if (sl.h_out) (void)hipHostFree(sl.h_out);
             if (sl.h_iters) (void)hipHostFree(sl.h_iters);
+            if (sl.h_head) (void)hipHostFree(sl.h_head);
             if (sl.h2d_done) (void)hipEventDestroy(sl.h2d_done);
             if (sl.all_done) (void)hipEventDestroy(sl.all_done);
         }
@@ -997,10 +999,9 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
     return LDPC_OK;
 }
 
-/* ldpc_decode on ONE device.  caller_pinned: the caller (the multi-device path) has already
- * page-locked the whole input range. */
+/* ldpc_decode on ONE device. */
 static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t *out_host,
-                       int64_t out_bytes, int32_t *iters, bool caller_pinned)
+                       int64_t out_bytes, int32_t *iters)
 {
     const int64_t total = ldpc_out_bytes(d->cfg.K, frames, d->cfg.pack_mode);
     HIP_TRY(hipSetDevice(d->cfg.device));
@@ -1023,6 +1024,7 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
         HIP_TRY(sl.iters.alloc((size_t)B));
         HIP_TRY(hipHostMalloc((void **)&sl.h_out, (size_t)stage_out, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc((void **)&sl.h_iters, (size_t)B * sizeof(int32_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&sl.h_head, 4096, hipHostMallocDefault));
         HIP_TRY(hipEventCreateWithFlags(&sl.h2d_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sl.all_done, hipEventDisableTiming));
     }
@@ -1036,18 +1038,17 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
         return LDPC_OK;
     };
     /* A copy from pageable memory waits for the device's other work (measured: 151 ms behind a
-     * 140 ms decode instead of 19 ms); page-locking the caller's input for the duration of the call
-     * makes every group's copy a true DMA that runs beside the previous group's kernels.  The whole
-     * range is registered ONCE (adjacent groups share pages) and released only after both streams
-     * have drained.  If the range cannot be registered (e.g. the caller has already page-locked it,
-     * or another call is decoding the same buffer) the copies simply stay pageable. */
-    bool own_pin = false;
-    if (nslots > 1 && !caller_pinned) {
-        if (hipHostRegister((void *)llr_host, (size_t)frames * d->N * sizeof(float), hipHostRegisterPortable) == hipSuccess)
-            own_pin = true;
-        else
-            (void)hipGetLastError();
-    }
+     * 140 ms decode instead of 19 ms), so from the second group on the caller's pages are page-locked
+     * for the duration of the call: a true DMA that runs beside the previous group's kernels.
+     * Group k >= 1 owns the block from its first page boundary up to the next group's first page
+     * boundary: blocks are page-disjoint (two registrations never share a page, neither within this
+     * call nor with the neighbouring frame range of another device's thread), each is registered
+     * just before its copy -- i.e. while the previous group decodes -- and all are released only
+     * after both streams have drained.  The few bytes of a group that lie before its first page
+     * boundary are read by the CPU into a pinned scratch page.  Group 0 is copied as it is: nothing
+     * of this call runs yet that it could overlap with.  A block that cannot be registered (already
+     * page-locked by the caller, or by another call decoding the same buffer) is copied pageable. */
+    std::vector<void *> pinned;
     int rc = LDPC_OK;
 #ifdef LDPC_TRACE_HOST
     const auto t_start = std::chrono::steady_clock::now();
@@ -1065,8 +1066,25 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
         const int r1 = drain(sl);                /* the slot's previous tenant (group kk - nslots) */
         if (r1) return r1;
         const int64_t off = kk * B, n = std::min(B, frames - off);
-        const float *src = llr_host + (size_t)off * d->N;
-        hipError_t e = hipMemcpyAsync(sl.llr.p, src, (size_t)n * d->N * sizeof(float), hipMemcpyHostToDevice, d->copy_stream);
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(llr_host + (size_t)off * d->N);
+        const size_t bytes = (size_t)n * d->N * sizeof(float);
+        const uintptr_t s0 = (uintptr_t)src, s1 = s0 + bytes, b0 = (s0 + 4095) & ~(uintptr_t)4095;
+        hipError_t e = hipSuccess;
+        if (kk >= 1 && b0 < s1) {
+            const uintptr_t b1 = kk + 1 < ngroups ? ((s1 + 4095) & ~(uintptr_t)4095) : s1;
+            if (hipHostRegister((void *)b0, (size_t)(b1 - b0), hipHostRegisterPortable) == hipSuccess) pinned.push_back((void *)b0);
+            else (void)hipGetLastError();
+            const size_t head = (size_t)(b0 - s0);
+            if (head) {
+                memcpy(sl.h_head, src, head);
+                e = hipMemcpyAsync(sl.llr.p, sl.h_head, head, hipMemcpyHostToDevice, d->copy_stream);
+            }
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(reinterpret_cast<uint8_t *>(sl.llr.p) + head, (const void *)b0, bytes - head,
+                                   hipMemcpyHostToDevice, d->copy_stream);
+        } else {
+            e = hipMemcpyAsync(sl.llr.p, src, bytes, hipMemcpyHostToDevice, d->copy_stream);
+        }
         if (e == hipSuccess) e = hipEventRecord(sl.h2d_done, d->copy_stream);
         if (e != hipSuccess) return fail(LDPC_ERR_HIP, "host-to-device staging: %s", hipGetErrorString(e));
         LDPC_STAMP("H2D enqueued", kk);
@@ -1105,7 +1123,7 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
     /* every exit path: nothing of this call is in flight any more when the pages are released */
     (void)hipStreamSynchronize(d->copy_stream);
     (void)hipStreamSynchronize(d->stream);
-    if (own_pin) (void)hipHostUnregister((void *)llr_host);
+    for (void *p : pinned) (void)hipHostUnregister(p);
     if (!first_error.empty()) g_err = first_error;
     return rc;
 }
@@ -1135,7 +1153,7 @@ int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
     if (frames == 0) return LDPC_OK;
     if (!llr_host || !out_host) return fail(LDPC_ERR_ARG, "llr/out is NULL");
     if (out_bytes < 0) return fail(LDPC_ERR_ARG, "out_bytes < 0");
-    if (d->shards.empty()) return decode_host(d, llr_host, frames, out_host, out_bytes, iters, false);
+    if (d->shards.empty()) return decode_host(d, llr_host, frames, out_host, out_bytes, iters);
 
     /* several devices: one host thread per device decodes a contiguous frame range */
     const int n = (int)d->shards.size();
@@ -1147,14 +1165,7 @@ int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
         if (rc) return rc;
         active += hi[i] > lo[i];
     }
-    bool pinned = false;
-    if (active > 1 || frames > d->cfg.max_batch) {
-        (void)hipSetDevice(d->shards[0]->cfg.device);
-        if (hipHostRegister((void *)llr_host, (size_t)frames * d->N * sizeof(float), hipHostRegisterPortable) == hipSuccess)
-            pinned = true;
-        else
-            (void)hipGetLastError();
-    }
+    (void)active;
     std::vector<int> rcs((size_t)n, LDPC_OK);
     std::vector<std::string> errs((size_t)n);
     auto work = [&](int i) {
@@ -1165,14 +1176,13 @@ int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
         const int64_t room = std::max<int64_t>(0, out_bytes - base);
         rcs[i] = decode_host(sh, llr_host + (size_t)lo[i] * d->N, hi[i] - lo[i], out_host + base,
                              std::min(room, ldpc_out_bytes(d->cfg.K, hi[i] - lo[i], d->cfg.pack_mode)),
-                             iters ? iters + lo[i] : nullptr, pinned);
+                             iters ? iters + lo[i] : nullptr);
         if (rcs[i]) errs[i] = g_err;
     };
     std::vector<std::thread> threads;
     for (int i = 1; i < n; ++i) threads.emplace_back(work, i);
     work(0);
     for (auto &t : threads) t.join();
-    if (pinned) (void)hipHostUnregister((void *)llr_host);
     for (int i = 0; i < n; ++i)
         if (rcs[i]) { g_err = errs[i]; return rcs[i]; }
     d->have_last = true;

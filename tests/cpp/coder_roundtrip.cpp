@@ -53,7 +53,7 @@ int main(int argc, char **argv)
     char *srcCode = (char *)malloc(srcLength);
     char *priorCode = (char *)malloc(coder.getPriorCodeLength(srcLength));
     float *postCode = (float *)malloc(sizeof(float) * coder.getPostCodeLength(srcLength));
-    char *newSrcCode = (char *)malloc(srcLength + 1);
+    char *newSrcCode = (char *)calloc(srcLength + 1, 1);   // bytes no frame covers (K % 8 != 0) stay 0
     for (int i = 0; i < srcLength; i++) srcCode[i] = 'a' + i % 26;     // Test.cpp:43-45
 
     if (coder.forEncoder()) { cout << "forEncoder failed: " << coder.lastError() << endl; return 1; }
