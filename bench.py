@@ -248,6 +248,7 @@ def main():
                     help="gloo: rehearsal of the N > 1 flow on fewer GPUs than ranks (collectives on CPU copies)")
     ap.add_argument("--sigma", type=float, default=0.0, help="extra configs: noise level override")
     ap.add_argument("--fpl", type=int, default=0, help="frames per lane override (tuning)")
+    ap.add_argument("--tune", default="", help='tuning fields as JSON, e.g. \'{"merge": false}\' (A/B experiments)')
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -286,7 +287,8 @@ def main():
     rows, cols = codes.dvbs2_profile_edges(N_CODE, K_CODE)
     g = L.Graph(rows, cols, N_CODE - K_CODE, N_CODE)
     dec = L.Decoder(g, K_CODE, max_batch=B, algo=args.algo, max_iter=ITERS, llr_scale=8.0,
-                    early_term=True, device=local_rank, frames_per_lane=args.fpl)
+                    early_term=True, device=local_rank, frames_per_lane=args.fpl,
+                    tune=json.loads(args.tune) if args.tune else None)
     # synthetic channel: all-zero codeword + AWGN, generated in HBM, distinct per rank
     lo, hi = sharding.shard_range(B * world, rank, world)
     # (counter-based noise, csrc/ldpc_channel.h: frame lo + i of the seed's stream, whatever the world size)

@@ -251,9 +251,65 @@ __global__ __launch_bounds__(kBlock) void check_kernel(const CheckArgs a)
     }
 }
 
-/* Any degree, run-time loops; only used above kMaxUnrolledDegree.  Min-sum: two passes
- * over the row.  Sum-product: the exact left-to-right product needs one pass per output, as
- * the reference does (L1/L2 serve the repeats). */
+/* One row of any degree with run-time loops (rows wider than the unrolled kernels, and the few
+ * left-over rows a linked check launch takes along).  Min-sum: two passes over the row.  Sum-product:
+ * the exact left-to-right product needs one pass per output, as the reference does (L1/L2 serve the
+ * repeats).  Qt / Rt: this lane's V values of the tile. */
+template <int ALGO, int V, typename T>
+__device__ __forceinline__ void check_row_generic(const T *Qt, T *Rt, int e0, int D)
+{
+    constexpr size_t F = 64 * V;
+    if (ALGO == kAlgoMS) {
+        /* two passes over the row instead of one per output: min1/min2/argmin and the sign
+         * parity first, then each output from its own re-read value (L2 serves the re-read) */
+        float m1[V], m2[V];
+        int idx[V];
+        unsigned par[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) { m1[v] = 1000.0f; m2[v] = 1000.0f; idx[v] = -1; par[v] = 0; }
+        for (int j = 0; j < D; ++j) {
+            float xj[V];
+            vload<V>(xj, Qt + (size_t)(e0 + j) * F);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const float m = __builtin_fabsf(xj[v]);
+                par[v] ^= (xj[v] < 0.0f) ? 1u : 0u;
+                if (m < m1[v]) { m2[v] = m1[v]; m1[v] = m; idx[v] = j; }
+                else if (m < m2[v]) { m2[v] = m; }
+            }
+        }
+        for (int k = 0; k < D; ++k) {
+            float xk[V], o[V];
+            vload<V>(xk, Qt + (size_t)(e0 + k) * F);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const float b = (k == idx[v]) ? m2[v] : m1[v];
+                const unsigned sg = par[v] ^ ((xk[v] < 0.0f) ? 1u : 0u);
+                o[v] = sg ? -b : b;
+            }
+            vstore<V>(Rt + (size_t)(e0 + k) * F, o);
+        }
+        return;
+    }
+    for (int k = 0; k < D; ++k) {
+        float o[V];
+        float p[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) p[v] = 1.0f;
+        for (int j = 0; j < D; ++j) {
+            if (j == k) continue;
+            float xj[V];
+            vload<V>(xj, Qt + (size_t)(e0 + j) * F);
+#pragma unroll
+            for (int v = 0; v < V; ++v) p[v] *= xj[v];
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) o[v] = p[v];
+        vstore<V>(Rt + (size_t)(e0 + k) * F, o);
+    }
+}
+
+/* Any degree; only launched above the unrolled degrees. */
 template <int ALGO, int V, typename T>
 __global__ __launch_bounds__(kBlock) void check_kernel_generic(const CheckArgs a)
 {
@@ -264,60 +320,73 @@ __global__ __launch_bounds__(kBlock) void check_kernel_generic(const CheckArgs a
     const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
     const int r_begin = wave * a.rows_per_wave;
     const int r_end = min(r_begin + a.rows_per_wave, a.n_rows);
-    const int D = a.degree;
     const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
     T *Rt = static_cast<T *>(a.R) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    for (int r = r_begin; r < r_end; ++r) check_row_generic<ALGO, V, T>(Qt, Rt, a.cls_e0[r], a.degree);
+}
+
+/* ---- several degree classes in ONE launch -------------------------------------------------
+ * A round used to cost one launch per row / column degree class (DVB-S2 rate 1/2: 2 + 4, two of
+ * them a single row / column).  A group launch covers every class of a degree bucket: the table
+ * says which block range belongs to which class, the block's (wave-uniform) degree picks the
+ * unrolled body.  Same bodies, same operation order, same bits; registers are those of the
+ * bucket's widest degree, hence the buckets. */
+struct GroupClass {
+    int32_t block_begin;        /* first blockIdx.x of this class */
+    int32_t degree;
+    int32_t count;              /* rows / columns */
+    int32_t pad;
+    const int32_t *ids;         /* rows: first edge ids; columns: column ids */
+    const int32_t *edges;       /* columns: [count][degree] edge ids */
+};
+
+template <int ALGO, int D, int V, int W, typename T>
+__device__ __forceinline__ void check_rows(const T *Qt, T *Rt, const int32_t *__restrict__ e0s, int r_begin, int r_end)
+{
+    constexpr size_t F = 64 * V;
     for (int r = r_begin; r < r_end; ++r) {
-        const int e0 = a.cls_e0[r];
-        if (ALGO == kAlgoMS) {
-            /* two passes over the row instead of one per output: min1/min2/argmin and the sign
-             * parity first, then each output from its own re-read value (L2 serves the re-read) */
-            float m1[V], m2[V];
-            int idx[V];
-            unsigned par[V];
+        const int e0 = e0s[r];
+        float x[D][W], out[D][W];
 #pragma unroll
-            for (int v = 0; v < V; ++v) { m1[v] = 1000.0f; m2[v] = 1000.0f; idx[v] = -1; par[v] = 0; }
-            for (int j = 0; j < D; ++j) {
-                float xj[V];
-                vload<V>(xj, Qt + (size_t)(e0 + j) * F);
+        for (int k = 0; k < D; ++k) vload<W>(x[k], Qt + (size_t)(e0 + k) * F);
+        if (ALGO == kAlgoSP) check_sp<D, W>(x, out); else check_ms<D, W>(x, out);
 #pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    const float m = __builtin_fabsf(xj[v]);
-                    par[v] ^= (xj[v] < 0.0f) ? 1u : 0u;
-                    if (m < m1[v]) { m2[v] = m1[v]; m1[v] = m; idx[v] = j; }
-                    else if (m < m2[v]) { m2[v] = m; }
-                }
-            }
-            for (int k = 0; k < D; ++k) {
-                float xk[V], o[V];
-                vload<V>(xk, Qt + (size_t)(e0 + k) * F);
-#pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    const float b = (k == idx[v]) ? m2[v] : m1[v];
-                    const unsigned sg = par[v] ^ ((xk[v] < 0.0f) ? 1u : 0u);
-                    o[v] = sg ? -b : b;
-                }
-                vstore<V>(Rt + (size_t)(e0 + k) * F, o);
-            }
-            continue;
-        }
-        for (int k = 0; k < D; ++k) {
-            float o[V];
-            float p[V];
-#pragma unroll
-            for (int v = 0; v < V; ++v) p[v] = 1.0f;
-            for (int j = 0; j < D; ++j) {
-                if (j == k) continue;
-                float xj[V];
-                vload<V>(xj, Qt + (size_t)(e0 + j) * F);
-#pragma unroll
-                for (int v = 0; v < V; ++v) p[v] *= xj[v];
-            }
-#pragma unroll
-            for (int v = 0; v < V; ++v) o[v] = p[v];
-            vstore<V>(Rt + (size_t)(e0 + k) * F, o);
-        }
+        for (int k = 0; k < D; ++k) vstore<W>(Rt + (size_t)(e0 + k) * F, out[k]);
     }
+}
+
+template <int ALGO, int V, typename T, int D, int DLO> struct CheckDispatch {
+    static __device__ __forceinline__ void run(int deg, const T *Qt, T *Rt, const int32_t *e0s, int rb, int re)
+    {
+        if (deg == D) check_rows<ALGO, D, V, 1, T>(Qt, Rt, e0s, rb, re);
+        else CheckDispatch<ALGO, V, T, D - 1, DLO>::run(deg, Qt, Rt, e0s, rb, re);
+    }
+};
+template <int ALGO, int V, typename T, int DLO> struct CheckDispatch<ALGO, V, T, DLO, DLO> {
+    static __device__ __forceinline__ void run(int, const T *Qt, T *Rt, const int32_t *e0s, int rb, int re)
+    {
+        check_rows<ALGO, DLO, V, 1, T>(Qt, Rt, e0s, rb, re);
+    }
+};
+
+/* narrow waves (1 value per lane), degrees DLO..DHI */
+template <int ALGO, int V, typename T, int DLO, int DHI>
+__global__ __launch_bounds__(kBlock) void check_group_kernel(const CheckArgs a, const GroupClass *__restrict__ cls, int n_classes)
+{
+    constexpr size_t F = 64 * V;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.y;
+    if (tile_finished<V>(a.done, tile)) return;
+    int c = 0;
+    while (c + 1 < n_classes && (int)blockIdx.x >= cls[c + 1].block_begin) ++c;
+    const int wave = ((int)blockIdx.x - cls[c].block_begin) * kWavesPerBlock + wave_id_in_block();
+    const int sub = wave % V;
+    const int r_begin = (wave / V) * a.rows_per_wave;
+    const int r_end = min(r_begin + a.rows_per_wave, cls[c].count);
+    const size_t lane_off = (size_t)sub * 64 + (size_t)lane;
+    const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + lane_off;
+    T *Rt = static_cast<T *>(a.R) + (size_t)tile * (size_t)a.E * F + lane_off;
+    CheckDispatch<ALGO, V, T, DHI, DLO>::run(cls[c].degree, Qt, Rt, cls[c].ids, r_begin, r_end);
 }
 
 /* checkResult, decodeCL.c:88-108, on the bit masks: one thread per row XORs the
@@ -467,7 +536,26 @@ struct LinkArgs {
     int32_t N;
     int32_t write_q;
     int32_t store_all;                     /* debug taps: also store the fused columns' R */
+    /* the few rows of OTHER degrees that are not worth a launch of their own (an IRA code's first row):
+     * blocks from link_blocks on take one each per wave, run-time loops */
+    const int32_t *__restrict__ extra_e0;  /* [n_extra] first edge id */
+    const int32_t *__restrict__ extra_deg; /* [n_extra] */
+    int32_t n_extra;
+    int32_t link_blocks;                   /* gridDim.x of the linked rows proper */
 };
+
+/* the trailing blocks of a linked check launch: one left-over row per wave, V values per lane */
+template <int ALGO, int V, typename T>
+__device__ __forceinline__ void link_extra_rows(const CheckArgs &a, const LinkArgs &g, int tile)
+{
+    constexpr size_t F = 64 * V;
+    const int lane = threadIdx.x & 63;
+    const int w = ((int)blockIdx.x - g.link_blocks) * kWavesPerBlock + wave_id_in_block();
+    if (w >= g.n_extra) return;
+    const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    T *Rt = static_cast<T *>(a.R) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    check_row_generic<ALGO, V, T>(Qt, Rt, g.extra_e0[w], g.extra_deg[w]);
+}
 
 template <int ALGO, int D, int V, typename T>
 __global__ __launch_bounds__(kBlock) void check_link_kernel(const CheckArgs a, const LinkArgs g)
@@ -476,6 +564,7 @@ __global__ __launch_bounds__(kBlock) void check_link_kernel(const CheckArgs a, c
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.y;
     if (tile_finished<V>(a.done, tile)) return;
+    if ((int)blockIdx.x >= g.link_blocks) { link_extra_rows<ALGO, V, T>(a, g, tile); return; }
     const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
     const int r_begin = wave * a.rows_per_wave;
     const int r_end = min(r_begin + a.rows_per_wave, a.n_rows);
@@ -618,6 +707,7 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow_kernel(const CheckAr
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.y;
     if (tile_finished<V>(a.done, tile)) return;
+    if ((int)blockIdx.x >= g.link_blocks) { link_extra_rows<ALGO, V, T>(a, g, tile); return; }
     const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
     const int sub = wave % V;
     const int r_begin = (wave / V) * a.rows_per_wave;
@@ -726,30 +816,20 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow_kernel(const CheckAr
 /* The variable node keeps WIDE waves (V values per lane, whole 64*V-frame segments per
  * wave-instruction): narrow waves as in check_kernel were measured 10 % slower here
  * (1.69 vs 1.53 ms per round at B = 4096), 2 values per lane no faster (1.11 vs 1.12 ms) --
- * the gather prefers fewer, larger requests. */
+ * the gather prefers fewer, larger requests.  Segments twice as large would not help either:
+ * tools/gather_probe.hip moves this exact traffic at 94-95 % of the box's copy rate with 1-, 2- and
+ * 4-KiB segments alike (profiles/r02_gather_probe.txt). */
 template <int ALGO, int D, int V, typename T>
-__global__ __launch_bounds__(kBlock) void var_kernel(const VarArgs a)
+__device__ __forceinline__ void var_columns(const T *Rt, T *Qt, const T *chan_t, uint64_t *hard_t, const uint64_t (&frozen)[V],
+                                            const int32_t *__restrict__ cls_col, const int32_t *__restrict__ cls_edge,
+                                            int c_begin, int c_end, int write_q, int lane)
 {
     constexpr size_t F = 64 * V;
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.y;
-    if (tile_finished<V>(a.done, tile)) return;
-    const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
-    const int c_begin = wave * a.cols_per_wave;
-    const int c_end = min(c_begin + a.cols_per_wave, a.n_cols);
-    const T *Rt = static_cast<const T *>(a.R) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
-    T *Qt = static_cast<T *>(a.Q) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
-    const T *chan_t = static_cast<const T *>(a.chan) + (size_t)tile * (size_t)a.N * F + (size_t)lane * V;
-    uint64_t *hard_t = a.hard + (size_t)tile * (size_t)a.N * V;
-    uint64_t frozen[V];
-#pragma unroll
-    for (int v = 0; v < V; ++v) frozen[v] = a.done[(size_t)tile * V + v];
-
     for (int ci = c_begin; ci < c_end; ++ci) {
-        const int n = a.cls_col[ci];
+        const int n = cls_col[ci];
         int e[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) e[k] = a.cls_edge[(size_t)ci * D + k];
+        for (int k = 0; k < D; ++k) e[k] = cls_edge[(size_t)ci * D + k];
         float ch[V], r[D][V], q[D][V];
         vload<V>(ch, chan_t + (size_t)n * F);
 #pragma unroll
@@ -785,11 +865,73 @@ __global__ __launch_bounds__(kBlock) void var_kernel(const VarArgs a)
             for (int v = 0; v < V; ++v)
                 hard_t[(size_t)n * V + v] = (old_w[v] & frozen[v]) | (new_w[v] & ~frozen[v]);
         }
-        if (a.write_q) {
+        if (write_q) {
 #pragma unroll
             for (int k = 0; k < D; ++k) vstore<V>(Qt + (size_t)e[k] * F, q[k]);
         }
     }
+}
+
+template <int ALGO, int D, int V, typename T>
+__global__ __launch_bounds__(kBlock) void var_kernel(const VarArgs a)
+{
+    constexpr size_t F = 64 * V;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.y;
+    if (tile_finished<V>(a.done, tile)) return;
+    const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
+    const int c_begin = wave * a.cols_per_wave;
+    const int c_end = min(c_begin + a.cols_per_wave, a.n_cols);
+    const T *Rt = static_cast<const T *>(a.R) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    T *Qt = static_cast<T *>(a.Q) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    const T *chan_t = static_cast<const T *>(a.chan) + (size_t)tile * (size_t)a.N * F + (size_t)lane * V;
+    uint64_t *hard_t = a.hard + (size_t)tile * (size_t)a.N * V;
+    uint64_t frozen[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) frozen[v] = a.done[(size_t)tile * V + v];
+    var_columns<ALGO, D, V, T>(Rt, Qt, chan_t, hard_t, frozen, a.cls_col, a.cls_edge, c_begin, c_end, a.write_q, lane);
+}
+
+template <int ALGO, int V, typename T, int D, int DLO> struct VarDispatch {
+    static __device__ __forceinline__ void run(int deg, const T *Rt, T *Qt, const T *chan_t, uint64_t *hard_t,
+                                               const uint64_t (&frozen)[V], const int32_t *col, const int32_t *edge,
+                                               int cb, int ce, int write_q, int lane)
+    {
+        if (deg == D) var_columns<ALGO, D, V, T>(Rt, Qt, chan_t, hard_t, frozen, col, edge, cb, ce, write_q, lane);
+        else VarDispatch<ALGO, V, T, D - 1, DLO>::run(deg, Rt, Qt, chan_t, hard_t, frozen, col, edge, cb, ce, write_q, lane);
+    }
+};
+template <int ALGO, int V, typename T, int DLO> struct VarDispatch<ALGO, V, T, DLO, DLO> {
+    static __device__ __forceinline__ void run(int, const T *Rt, T *Qt, const T *chan_t, uint64_t *hard_t,
+                                               const uint64_t (&frozen)[V], const int32_t *col, const int32_t *edge,
+                                               int cb, int ce, int write_q, int lane)
+    {
+        var_columns<ALGO, DLO, V, T>(Rt, Qt, chan_t, hard_t, frozen, col, edge, cb, ce, write_q, lane);
+    }
+};
+
+/* every column class of the degree bucket DLO..DHI in one launch (GroupClass table above) */
+template <int ALGO, int V, typename T, int DLO, int DHI>
+__global__ __launch_bounds__(kBlock) void var_group_kernel(const VarArgs a, const GroupClass *__restrict__ cls, int n_classes)
+{
+    constexpr size_t F = 64 * V;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.y;
+    if (tile_finished<V>(a.done, tile)) return;
+    int c = 0;
+    while (c + 1 < n_classes && (int)blockIdx.x >= cls[c + 1].block_begin) ++c;
+    const int wave = ((int)blockIdx.x - cls[c].block_begin) * kWavesPerBlock + wave_id_in_block();
+    const int c_begin = wave * a.cols_per_wave;
+    const int c_end = min(c_begin + a.cols_per_wave, cls[c].count);
+    const T *Rt = static_cast<const T *>(a.R) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    T *Qt = static_cast<T *>(a.Q) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    const T *chan_t = static_cast<const T *>(a.chan) + (size_t)tile * (size_t)a.N * F + (size_t)lane * V;
+    uint64_t *hard_t = a.hard + (size_t)tile * (size_t)a.N * V;
+    uint64_t frozen[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) frozen[v] = a.done[(size_t)tile * V + v];
+    VarDispatch<ALGO, V, T, DHI, DLO>::run(cls[c].degree, Rt, Qt, chan_t, hard_t, frozen, cls[c].ids, cls[c].edges,
+                                           c_begin, c_end, a.write_q, lane);
 }
 
 template <int ALGO, int V, typename T>

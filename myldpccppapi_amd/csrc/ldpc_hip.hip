@@ -64,6 +64,15 @@ int fail(int code, const char *fmt, ...)
 template <typename T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept
+    {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
     hipError_t alloc(size_t count)
     {
         release();
@@ -149,6 +158,31 @@ template <int ALGO, int V, typename T> struct LinkTable<ALGO, V, T, 1> {
     static void fill(LinkFn *, LinkFn *) {}
 };
 
+/* group launches (several degree classes of a bucket in one launch, flood_kernels.hpp) */
+using CheckGroupFn = void (*)(const ldpc::CheckArgs, const ldpc::GroupClass *, int);
+using VarGroupFn = void (*)(const ldpc::VarArgs, const ldpc::GroupClass *, int);
+constexpr int kVarBuckets = 3, kCheckBuckets = 4;
+constexpr int kVarBucketLo[kVarBuckets] = {1, 5, 9}, kVarBucketHi[kVarBuckets] = {4, 8, 16};
+constexpr int kCheckBucketLo[kCheckBuckets] = {1, 9, 17, 25}, kCheckBucketHi[kCheckBuckets] = {8, 16, 24, 32};
+template <int ALGO, int V, typename T> struct GroupTable {
+    static void fill(CheckGroupFn *c, VarGroupFn *v)
+    {
+        c[0] = ldpc::check_group_kernel<ALGO, V, T, 1, 8>;
+        c[1] = ldpc::check_group_kernel<ALGO, V, T, 9, 16>;
+        c[2] = c[3] = nullptr;
+        v[0] = ldpc::var_group_kernel<ALGO, V, T, 1, 4>;
+        v[1] = ldpc::var_group_kernel<ALGO, V, T, 5, 8>;
+        v[2] = ldpc::var_group_kernel<ALGO, V, T, 9, 16>;
+    }
+};
+template <int V, typename T> struct GroupTableMSWide {     /* min-sum rows of degree 17..32 */
+    static void fill(CheckGroupFn *c)
+    {
+        c[2] = ldpc::check_group_kernel<ldpc::kAlgoMS, V, T, 17, 24>;
+        c[3] = ldpc::check_group_kernel<ldpc::kAlgoMS, V, T, 25, 32>;
+    }
+};
+
 using InitFn = void (*)(const ldpc::InitArgs);
 template <int ALGO, typename T> InitFn pick_init(int V)
 {
@@ -160,6 +194,7 @@ struct RowClass {
     int degree = 0;
     int count = 0;
     DevBuf<int32_t> e0;
+    std::vector<int32_t> h_e0;
     /* column-local fusion (check_link_kernel): per list row, the degree-2 column shared with
      * the next list row when both fall in one wave's chunk of link_rpw rows */
     DevBuf<int32_t> link_col, link_pos;
@@ -171,12 +206,21 @@ struct ColClass {
     DevBuf<int32_t> col, edge;
 };
 
+/* the classes of one degree bucket that share a launch */
+struct ClassGroup {
+    int bucket = 0, lo = 0, hi = 0;
+    int blocks = 0;                       /* gridDim.x */
+    std::vector<int> members;             /* indices into row_classes / col_classes */
+    DevBuf<ldpc::GroupClass> table;
+};
+
 struct TimedSpan {
     hipEvent_t a, b;
-    int kind;       /* 0 check, 1 var, 2 layer, 3 other, 4 check with column-local fusion */
-    int degree;
+    int kind;       /* 0 check, 1 var, 2 layer, 3 other, 4 check with column-local fusion, 5 check group, 6 var group */
+    int degree;     /* groups: the bucket's highest degree */
     int64_t bytes;  /* algorithmic bytes of the launch in the two-kernel formulation (16 E + 4 N in total) */
     int64_t moved;  /* bytes this kernel's own loads and stores move (less when columns are fused in) */
+    int lo;         /* groups: the bucket's lowest degree */
 };
 
 }  // namespace
@@ -196,6 +240,15 @@ struct ldpc_decoder {
     DevBuf<int32_t> iters, active;
     std::vector<RowClass> row_classes;
     std::vector<ColClass> col_classes;
+    /* launch plan of a round (plan_launches): classes that share a launch, classes launched alone,
+     * and the left-over rows a linked check launch takes along */
+    std::vector<ClassGroup> check_groups, var_groups;
+    std::vector<int> check_solo, var_solo;
+    CheckGroupFn check_group_fn[kCheckBuckets] = {};
+    VarGroupFn var_group_fn[kVarBuckets] = {};
+    DevBuf<int32_t> extra_e0, extra_deg;
+    int n_extra = 0;
+    int64_t extra_edges = 0;
     CheckFn check_fn[ldpc::kMaxUnrolledCheckDegreeMS + 1] = {};      /* narrow waves (1 value per lane) */
     CheckFn check_fn_wide[ldpc::kMaxUnrolledCheckDegreeMS + 1] = {}; /* V values per lane */
     int max_check_unrolled = ldpc::kMaxUnrolledDegree;
@@ -308,7 +361,8 @@ int pick_frames_per_lane(const ldpc_decoder_config &cfg, int32_t max_row_deg, in
     return 1;
 }
 
-hipError_t span_begin(ldpc_decoder *d, hipStream_t s, int kind, int degree = 0, int64_t bytes = 0, int64_t moved = -1)
+hipError_t span_begin(ldpc_decoder *d, hipStream_t s, int kind, int degree = 0, int64_t bytes = 0, int64_t moved = -1,
+                      int lo = 0)
 {
     if (!d->timing) return hipSuccess;
     if (d->spans_used == d->spans.size()) {
@@ -323,6 +377,7 @@ hipError_t span_begin(ldpc_decoder *d, hipStream_t s, int kind, int degree = 0, 
     d->spans[d->spans_used].degree = degree;
     d->spans[d->spans_used].bytes = bytes;
     d->spans[d->spans_used].moved = moved < 0 ? bytes : moved;
+    d->spans[d->spans_used].lo = lo;
     return hipEventRecord(d->spans[d->spans_used].a, s);
 }
 
@@ -400,27 +455,39 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
     for (int it = start_round; it <= rounds; ++it) {
         /* check_i: R_i = check(Q_{i-1}) */
         for (auto &rc : d->row_classes) {
+            if (!rc.linked) continue;
             /* algorithmic bytes: the fused columns' messages and channel values count as in the
-             * two-kernel formulation (16 E + 4 N per frame-iteration in total) */
-            /* moved: every Q of the class and the fused columns' channel values in; R of the unfused
-             * edges and the fused columns' new Q out */
-            HIP_TRY(span_begin(d, s, rc.linked ? 4 : 0, rc.degree,
-                               (2 * msz * rc.degree * rc.count + msz * 5 * rc.linked) * frames,
+             * two-kernel formulation (16 E + 4 N per frame-iteration in total).
+             * moved: every Q of the class and the fused columns' channel values in; R of the unfused
+             * edges and the fused columns' new Q out.  Rows riding along: Q in, R out. */
+            HIP_TRY(span_begin(d, s, 4, rc.degree,
+                               (2 * msz * rc.degree * rc.count + msz * 5 * rc.linked + 2 * msz * d->extra_edges) * frames,
                                msz * ((int64_t)rc.degree * rc.count + rc.linked +
                                       ((int64_t)rc.degree * rc.count - 2 * rc.linked) +
-                                      (it < max_iter ? 2 * rc.linked : 0)) * frames));
+                                      (it < max_iter ? 2 * rc.linked : 0) + 2 * d->extra_edges) * frames));
             CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree};
-            if (rc.linked) {
-                LinkArgs lk{rc.link_col.p, rc.link_pos.p, d->chan.p, d->Q.p, d->hard.p, d->N,
-                            (it < max_iter) ? 1 : 0, d->tap_iter ? 1 : 0};
-                a.rows_per_wave = d->link_rpw;
-                const bool nar = d->tune_link_narrow != 0;
-                const int waves = ((rc.count + d->link_rpw - 1) / d->link_rpw) * (nar ? V : 1);
-                dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
-                (nar ? d->link_narrow_fn : d->link_fn)[rc.degree]<<<grid, kBlock, 0, s>>>(a, lk);
-                HIP_TRY(span_end(d, s));
-                continue;
-            }
+            LinkArgs lk{rc.link_col.p, rc.link_pos.p, d->chan.p, d->Q.p, d->hard.p, d->N,
+                        (it < max_iter) ? 1 : 0, d->tap_iter ? 1 : 0, d->extra_e0.p, d->extra_deg.p, d->n_extra, 0};
+            a.rows_per_wave = d->link_rpw;
+            const bool nar = d->tune_link_narrow != 0;
+            const int waves = ((rc.count + d->link_rpw - 1) / d->link_rpw) * (nar ? V : 1);
+            lk.link_blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+            dim3 grid(lk.link_blocks + (d->n_extra + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
+            (nar ? d->link_narrow_fn : d->link_fn)[rc.degree]<<<grid, kBlock, 0, s>>>(a, lk);
+            HIP_TRY(span_end(d, s));
+        }
+        for (auto &g : d->check_groups) {
+            int64_t edges = 0;
+            for (int i : g.members) edges += (int64_t)d->row_classes[i].degree * d->row_classes[i].count;
+            HIP_TRY(span_begin(d, s, 5, g.hi, 2 * msz * edges * frames, -1, g.lo));
+            CheckArgs a{d->Q.p, d->R.p, nullptr, d->done.p, d->E, 0, d->tune_rpw ? d->tune_rpw : 2, 0};
+            d->check_group_fn[g.bucket]<<<dim3(g.blocks, tiles), kBlock, 0, s>>>(a, g.table.p, (int)g.members.size());
+            HIP_TRY(span_end(d, s));
+        }
+        for (int ci : d->check_solo) {
+            RowClass &rc = d->row_classes[ci];
+            HIP_TRY(span_begin(d, s, 0, rc.degree, 2 * msz * rc.degree * rc.count * frames));
+            CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree};
             const int slotk = rc.degree <= d->max_check_unrolled ? rc.degree : 0;
             const bool narrow = slotk && (!d->tune_check_wide || rc.degree > kMaxUnrolledDegree);
             const int rpw = d->tune_rpw ? d->tune_rpw : (narrow ? 2 : 1);
@@ -431,11 +498,21 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             HIP_TRY(span_end(d, s));
         }
         /* var_i: bits_i = hard(R_i); Q_i = var(R_i) unless this is the last round */
-        for (auto &cc : d->col_classes) {
-            HIP_TRY(span_begin(d, s, 1, cc.degree,
-                               msz * ((it < max_iter ? 2 : 1) * cc.degree + 1) * cc.count * frames));
+        const int wq = (it < max_iter) ? 1 : 0;
+        for (auto &g : d->var_groups) {
+            int64_t units = 0;          /* messages read + written + channel values read, per frame */
+            for (int i : g.members) units += (int64_t)((wq ? 2 : 1) * d->col_classes[i].degree + 1) * d->col_classes[i].count;
+            HIP_TRY(span_begin(d, s, 6, g.hi, msz * units * frames, -1, g.lo));
+            VarArgs a{d->R.p, d->Q.p, d->chan.p, d->hard.p, d->done.p, nullptr, nullptr,
+                      d->E, d->N, 0, d->tune_cpw ? d->tune_cpw : 1, wq, 0};
+            d->var_group_fn[g.bucket]<<<dim3(g.blocks, tiles), kBlock, 0, s>>>(a, g.table.p, (int)g.members.size());
+            HIP_TRY(span_end(d, s));
+        }
+        for (int ci : d->var_solo) {
+            ColClass &cc = d->col_classes[ci];
+            HIP_TRY(span_begin(d, s, 1, cc.degree, msz * ((wq ? 2 : 1) * cc.degree + 1) * cc.count * frames));
             VarArgs a{d->R.p, d->Q.p, d->chan.p, d->hard.p, d->done.p, cc.col.p, cc.edge.p,
-                      d->E, d->N, cc.count, 1, (it < max_iter) ? 1 : 0, cc.degree};
+                      d->E, d->N, cc.count, 1, wq, cc.degree};
             const int cpw = d->tune_cpw ? d->tune_cpw : 1;
             a.cols_per_wave = cpw;
             const int slotk = cc.degree <= kMaxUnrolledDegree ? cc.degree : 0;
@@ -516,6 +593,7 @@ int build_classes(ldpc_decoder *d, const ldpc_graph *g)
         RowClass &rc = d->row_classes[i++];
         rc.degree = kv.first;
         rc.count = (int)kv.second.size();
+        rc.h_e0 = kv.second;
         HIP_TRY(rc.e0.upload(kv.second));
         const std::vector<int32_t> &ids = rowids_by_deg[kv.first];
         const int rpw = d->link_rpw;
@@ -567,6 +645,75 @@ int build_classes(ldpc_decoder *d, const ldpc_graph *g)
     return LDPC_OK;
 }
 
+/* Which classes share a launch (degree buckets), which go alone, and whether the few rows outside a
+ * linked class ride along with its launch.  LDPC_TUNE_OFF(LDPC_TUNE_MERGE): one launch per class. */
+int plan_launches(ldpc_decoder *d)
+{
+    using ldpc::GroupClass;
+    const int V = d->V;
+    const bool merge = ldpc::tune_pick(d->tune.merge, true) && !d->tune_check_wide;
+    d->check_groups.clear(); d->var_groups.clear(); d->check_solo.clear(); d->var_solo.clear();
+    d->n_extra = 0; d->extra_edges = 0;
+    int linked_classes = 0;
+    int64_t unlinked_rows = 0;
+    for (auto &rc : d->row_classes) { if (rc.linked) ++linked_classes; else unlinked_rows += rc.count; }
+    const bool as_extra = merge && linked_classes == 1 && unlinked_rows > 0 && unlinked_rows <= 64;
+    std::vector<int> cb[kCheckBuckets], vb[kVarBuckets];
+    std::vector<int32_t> xe0, xdeg;
+    for (int i = 0; i < (int)d->row_classes.size(); ++i) {
+        RowClass &rc = d->row_classes[i];
+        if (rc.linked) continue;
+        if (as_extra) {
+            for (int32_t e : rc.h_e0) { xe0.push_back(e); xdeg.push_back(rc.degree); d->extra_edges += rc.degree; }
+            continue;
+        }
+        int b = -1;
+        for (int k = 0; k < kCheckBuckets; ++k)
+            if (rc.degree >= kCheckBucketLo[k] && rc.degree <= kCheckBucketHi[k] && rc.degree <= d->max_check_unrolled &&
+                d->check_group_fn[k]) b = k;
+        if (merge && b >= 0) cb[b].push_back(i); else d->check_solo.push_back(i);
+    }
+    if (as_extra) {
+        d->n_extra = (int)xe0.size();
+        HIP_TRY(d->extra_e0.upload(xe0));
+        HIP_TRY(d->extra_deg.upload(xdeg));
+    }
+    for (int i = 0; i < (int)d->col_classes.size(); ++i) {
+        const ColClass &cc = d->col_classes[i];
+        int b = -1;
+        for (int k = 0; k < kVarBuckets; ++k)
+            if (cc.degree >= kVarBucketLo[k] && cc.degree <= kVarBucketHi[k] && d->var_group_fn[k]) b = k;
+        if (merge && b >= 0) vb[b].push_back(i); else d->var_solo.push_back(i);
+    }
+    const int rpw = d->tune_rpw ? d->tune_rpw : 2, cpw = d->tune_cpw ? d->tune_cpw : 1;
+    auto make = [&](std::vector<ClassGroup> &groups, std::vector<int> &solo, const std::vector<int> &members, int bucket,
+                    int lo, int hi, bool rows) -> hipError_t {
+        if (members.size() < 2) { for (int i : members) solo.push_back(i); return hipSuccess; }
+        groups.emplace_back();
+        ClassGroup &g = groups.back();
+        g.bucket = bucket; g.lo = lo; g.hi = hi; g.members = members;
+        std::vector<GroupClass> tab;
+        for (int i : members) {
+            GroupClass gc{};
+            gc.block_begin = g.blocks;
+            if (rows) {
+                const RowClass &rc = d->row_classes[i];
+                gc.degree = rc.degree; gc.count = rc.count; gc.ids = rc.e0.p; gc.edges = nullptr;
+                g.blocks += (((rc.count + rpw - 1) / rpw) * V + ldpc::kWavesPerBlock - 1) / ldpc::kWavesPerBlock;
+            } else {
+                const ColClass &cc = d->col_classes[i];
+                gc.degree = cc.degree; gc.count = cc.count; gc.ids = cc.col.p; gc.edges = cc.edge.p;
+                g.blocks += ((cc.count + cpw - 1) / cpw + ldpc::kWavesPerBlock - 1) / ldpc::kWavesPerBlock;
+            }
+            tab.push_back(gc);
+        }
+        return g.table.upload(tab);
+    };
+    for (int k = 0; k < kCheckBuckets; ++k) HIP_TRY(make(d->check_groups, d->check_solo, cb[k], k, kCheckBucketLo[k], kCheckBucketHi[k], true));
+    for (int k = 0; k < kVarBuckets; ++k) HIP_TRY(make(d->var_groups, d->var_solo, vb[k], k, kVarBucketLo[k], kVarBucketHi[k], false));
+    return LDPC_OK;
+}
+
 /* HBM message arrays, per-degree work lists and kernel tables of a streaming flooding decoder. */
 int setup_flooding(ldpc_decoder *d, const ldpc_graph *g, size_t TF)
 {
@@ -586,9 +733,11 @@ int setup_flooding(ldpc_decoder *d, const ldpc_graph *g, size_t TF)
     do {                                                                               \
         FloodTable<ALGO, VV, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn); \
         LinkTable<ALGO, VV, TYPE, DM>::fill(d->link_fn, d->link_narrow_fn);            \
+        GroupTable<ALGO, VV, TYPE>::fill(d->check_group_fn, d->var_group_fn);          \
         d->init_fn = pick_init<ALGO, TYPE>(VV);                                        \
         if (ALGO == kAlgoMS) {   /* min-sum rows of degree 17..32: narrow unrolled kernels */ \
             CheckTableMS<VV, TYPE, DH>::fill(d->check_fn, d->check_fn_wide);           \
+            GroupTableMSWide<VV, TYPE>::fill(d->check_group_fn);                       \
             d->max_check_unrolled = DH;                                                \
         }                                                                              \
     } while (0)
@@ -603,7 +752,7 @@ int setup_flooding(ldpc_decoder *d, const ldpc_graph *g, size_t TF)
     else LDPC_FILL_V(kAlgoMS, float);
 #undef LDPC_FILL_V
 #undef LDPC_FILL
-    return LDPC_OK;
+    return plan_launches(d);
 }
 
 }  // namespace
@@ -1246,8 +1395,9 @@ int ldpc_decoder_stats(ldpc_decoder *d, ldpc_decode_stats *st)
     for (size_t i = 0; i < d->spans_used; ++i) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, d->spans[i].a, d->spans[i].b));
-        if (d->spans[i].kind == 0 || d->spans[i].kind == 4) { st->ms_check += ms; ++st->launches_check; }
-        else if (d->spans[i].kind == 1 || d->spans[i].kind == 2) { st->ms_var += ms; ++st->launches_var; }
+        const int kind = d->spans[i].kind;
+        if (kind == 0 || kind == 4 || kind == 5) { st->ms_check += ms; ++st->launches_check; }
+        else if (kind == 1 || kind == 2 || kind == 6) { st->ms_var += ms; ++st->launches_var; }
         else st->ms_other += ms;
     }
     return LDPC_OK;
@@ -1270,22 +1420,27 @@ int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t ca
         const TimedSpan &sp = d->spans[i];
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, sp.a, sp.b));
+        const int phase = (sp.kind == 4 || sp.kind == 5) ? 0 : (sp.kind == 6 ? 1 : sp.kind);   /* check / variable node */
+        char name[64];
+        if (sp.kind == 3) snprintf(name, sizeof name, "other");
+        else if (d->use_fused)      /* whole decode in one launch; bytes = channel values in + packed bits out */
+            snprintf(name, sizeof name, "%s", d->use_ldsp ? (d->cfg.algo == LDPC_ALGO_LAYERED ? "layered_ldsp_kernel" : "flood_ldsp_kernel")
+                     : d->cfg.algo == LDPC_ALGO_SP ? "fused_sp_kernel"
+                     : d->cfg.algo == LDPC_ALGO_LAYERED ? "fused_layered_kernel" : "fused_flood_kernel");
+        else if (sp.kind == 5 || sp.kind == 6)
+            snprintf(name, sizeof name, "%s<%s,%d-%d,%d>", sp.kind == 5 ? "check_group_kernel" : "var_group_kernel",
+                     algo_name[d->cfg.algo], sp.lo, sp.degree, d->V);
+        else snprintf(name, sizeof name, "%s<%s,%d,%d>", phase_name[sp.kind], algo_name[d->cfg.algo], sp.degree, d->V);
         int k = 0;
         for (; k < *count; ++k)
-            if (out[k].phase == (sp.kind == 4 ? 0 : sp.kind) && out[k].degree == sp.degree) break;
+            if (!strcmp(out[k].name, name)) break;
         if (k == *count) {
             if (*count == capacity) continue;
             ++*count;
             memset(&out[k], 0, sizeof out[k]);
-            out[k].phase = sp.kind == 4 ? 0 : sp.kind;      /* both are the check phase */
+            out[k].phase = phase;
             out[k].degree = sp.degree;
-            if (sp.kind == 3) snprintf(out[k].name, sizeof out[k].name, "other");
-            else if (d->use_fused)      /* whole decode in one launch; bytes = channel values in + packed bits out */
-                snprintf(out[k].name, sizeof out[k].name, "%s", d->use_ldsp ? (d->cfg.algo == LDPC_ALGO_LAYERED ? "layered_ldsp_kernel" : "flood_ldsp_kernel")
-                         : d->cfg.algo == LDPC_ALGO_SP ? "fused_sp_kernel"
-                         : d->cfg.algo == LDPC_ALGO_LAYERED ? "fused_layered_kernel" : "fused_flood_kernel");
-            else snprintf(out[k].name, sizeof out[k].name, "%s<%s,%d,%d>", phase_name[sp.kind],
-                          algo_name[d->cfg.algo], sp.degree, d->V);
+            memcpy(out[k].name, name, sizeof name);
         }
         ++out[k].launches;
         out[k].ms_total += ms;
