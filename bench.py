@@ -56,7 +56,7 @@ EXTRA_CONFIGS = {
 }
 
 
-def measure_extra(name, steps, warmup, batch=0, sigma=0.0, fpl=0):
+def measure_extra(name, steps, warmup, batch=0, sigma=0.0, fpl=0, poll=-1, tune=None):
     """One extra config on the current GPU: dict with the headline fields of its own."""
     import numpy as np
     import torch
@@ -76,9 +76,11 @@ def measure_extra(name, steps, warmup, batch=0, sigma=0.0, fpl=0):
     B = batch or c["batch"]
     if sigma:
         c = dict(c, sigma=sigma, desc=c["desc"] + " [sigma override %.3f]" % sigma)
+    if poll >= 0:
+        c = dict(c, poll=poll, desc=c["desc"] + " [poll_interval %d]" % poll)
     g = L.Graph(rows, cols, M, N)
     dec = L.Decoder(g, K, max_batch=B, algo=c["algo"], max_iter=c["iters"], early_term=c["early"],
-                    layer_rows=layer, msg_dtype=c["msg"], poll_interval=c["poll"], frames_per_lane=fpl)
+                    layer_rows=layer, msg_dtype=c["msg"], poll_interval=c["poll"], frames_per_lane=fpl, tune=tune)
     y = channel.awgn_device(N, 0, B, c["sigma"], seed=SEED)
     out = torch.empty(L.out_bytes(K, B), dtype=torch.uint8, device="cuda")
     it = torch.empty(B, dtype=torch.int32, device="cuda")
@@ -248,6 +250,7 @@ def main():
                     help="gloo: rehearsal of the N > 1 flow on fewer GPUs than ranks (collectives on CPU copies)")
     ap.add_argument("--sigma", type=float, default=0.0, help="extra configs: noise level override")
     ap.add_argument("--fpl", type=int, default=0, help="frames per lane override (tuning)")
+    ap.add_argument("--poll", type=int, default=-1, help="extra configs: poll_interval override (0 = asynchronous)")
     ap.add_argument("--tune", default="", help='tuning fields as JSON, e.g. \'{"merge": false}\' (A/B experiments)')
     args = ap.parse_args()
 
@@ -277,7 +280,8 @@ def main():
     if args.config != "dvbs2_sp":
         if world > 1:
             sys.exit("extra configs are single-GPU measurements")
-        print(json.dumps(measure_extra(args.config, args.steps, args.warmup, args.batch, args.sigma, args.fpl)), flush=True)
+        print(json.dumps(measure_extra(args.config, args.steps, args.warmup, args.batch, args.sigma, args.fpl, args.poll,
+                                       json.loads(args.tune) if args.tune else None)), flush=True)
         return
 
     import myldpccppapi_amd as L

@@ -151,6 +151,30 @@ template <int V> __device__ __forceinline__ bool tile_finished(const uint64_t *d
     return all;
 }
 
+/* ---- device-side tail (early termination without host polling) --------------------------------
+ * An asynchronous caller has all max_iter rounds enqueued up front.  When only a few frames of a
+ * large batch are still running, tail_gather_kernel (below) moves their state into `n_tiles`
+ * OVERFLOW tiles that follow the batch's own tiles in every array and flips state[0]; from then on
+ * the blocks of the first n_tiles grid rows of every launch work on the overflow tiles and all
+ * other blocks leave at once -- the decision is taken on the device, no launch is added per round
+ * except the (empty) gather attempt.  state == nullptr: feature off. */
+struct TailRef {
+    const int32_t *state;   /* [0] handed over, [1] frames handed over, [2] round of the hand-over */
+    int32_t base_tile;      /* index of the first overflow tile = tiles of max_batch */
+    int32_t n_tiles;        /* overflow tiles */
+};
+
+/* The tile a block with grid row `row` works on, or -1 if it has nothing to do. */
+template <int V> __device__ __forceinline__ int tile_select(const TailRef &t, const uint64_t *done, int row)
+{
+    int tile = row;
+    if (t.state && __builtin_amdgcn_readfirstlane(t.state[0])) {
+        if (row >= t.n_tiles) return -1;
+        tile = t.base_tile + row;
+    }
+    return tile_finished<V>(done, tile) ? -1 : tile;
+}
+
 /* ========================================================================= */
 /*                               check node                                   */
 /* ========================================================================= */
@@ -164,6 +188,7 @@ struct CheckArgs {
     int32_t n_rows;
     int32_t rows_per_wave;
     int32_t degree;                      /* generic kernel only */
+    TailRef tail;
 };
 
 /* Sum-product, decodeCL.c:32-40: out_k = prod_{j != k} x_j, multiplied left to
@@ -230,8 +255,8 @@ __global__ __launch_bounds__(kBlock) void check_kernel(const CheckArgs a)
     constexpr size_t F = 64 * V;
     constexpr int SUB = V / W;
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.y;
-    if (tile_finished<V>(a.done, tile)) return;
+    const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
+    if (tile < 0) return;
     const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
     const int sub = wave % SUB;
     const int r_begin = (wave / SUB) * a.rows_per_wave;
@@ -315,8 +340,8 @@ __global__ __launch_bounds__(kBlock) void check_kernel_generic(const CheckArgs a
 {
     constexpr size_t F = 64 * V;
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.y;
-    if (tile_finished<V>(a.done, tile)) return;
+    const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
+    if (tile < 0) return;
     const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
     const int r_begin = wave * a.rows_per_wave;
     const int r_end = min(r_begin + a.rows_per_wave, a.n_rows);
@@ -375,8 +400,8 @@ __global__ __launch_bounds__(kBlock) void check_group_kernel(const CheckArgs a, 
 {
     constexpr size_t F = 64 * V;
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.y;
-    if (tile_finished<V>(a.done, tile)) return;
+    const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
+    if (tile < 0) return;
     int c = 0;
     while (c + 1 < n_classes && (int)blockIdx.x >= cls[c + 1].block_begin) ++c;
     const int wave = ((int)blockIdx.x - cls[c].block_begin) * kWavesPerBlock + wave_id_in_block();
@@ -401,6 +426,7 @@ struct SyndromeArgs {
     int32_t M, N;
     int32_t tiles;                        /* > 0: XCD-aware 1-D grid (see syndrome_kernel) */
     int32_t row_blocks;
+    TailRef tail;
 };
 
 template <int V> __global__ __launch_bounds__(kBlock) void syndrome_kernel(const SyndromeArgs a)
@@ -419,7 +445,8 @@ template <int V> __global__ __launch_bounds__(kBlock) void syndrome_kernel(const
         tile = blockIdx.y;
         rb = blockIdx.x;
     }
-    if (tile_finished<V>(a.done, tile)) return;
+    tile = tile_select<V>(a.tail, a.done, tile);
+    if (tile < 0) return;
     const int m = rb * kBlock + threadIdx.x;
     const uint64_t *hard_t = a.hard + (size_t)tile * (size_t)a.N * V;
     uint64_t s[V];
@@ -477,6 +504,7 @@ struct VarArgs {
     int32_t cols_per_wave;
     int32_t write_q;                      /* 0 on the last round (MyLdpc.cpp:1035-1040) */
     int32_t degree;                       /* generic kernel only */
+    TailRef tail;
 };
 
 /* Sum-product variable node: hardDecision (decodeCL.c:72-82) and refreshQ
@@ -562,8 +590,8 @@ __global__ __launch_bounds__(kBlock) void check_link_kernel(const CheckArgs a, c
 {
     constexpr size_t F = 64 * V;
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.y;
-    if (tile_finished<V>(a.done, tile)) return;
+    const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
+    if (tile < 0) return;
     if ((int)blockIdx.x >= g.link_blocks) { link_extra_rows<ALGO, V, T>(a, g, tile); return; }
     const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
     const int r_begin = wave * a.rows_per_wave;
@@ -705,8 +733,8 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow_kernel(const CheckAr
     constexpr size_t F = 64 * V;
     constexpr int FB = 64 / V;                       /* bits per field */
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.y;
-    if (tile_finished<V>(a.done, tile)) return;
+    const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
+    if (tile < 0) return;
     if ((int)blockIdx.x >= g.link_blocks) { link_extra_rows<ALGO, V, T>(a, g, tile); return; }
     const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
     const int sub = wave % V;
@@ -877,8 +905,8 @@ __global__ __launch_bounds__(kBlock) void var_kernel(const VarArgs a)
 {
     constexpr size_t F = 64 * V;
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.y;
-    if (tile_finished<V>(a.done, tile)) return;
+    const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
+    if (tile < 0) return;
     const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
     const int c_begin = wave * a.cols_per_wave;
     const int c_end = min(c_begin + a.cols_per_wave, a.n_cols);
@@ -916,8 +944,8 @@ __global__ __launch_bounds__(kBlock) void var_group_kernel(const VarArgs a, cons
 {
     constexpr size_t F = 64 * V;
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.y;
-    if (tile_finished<V>(a.done, tile)) return;
+    const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
+    if (tile < 0) return;
     int c = 0;
     while (c + 1 < n_classes && (int)blockIdx.x >= cls[c + 1].block_begin) ++c;
     const int wave = ((int)blockIdx.x - cls[c].block_begin) * kWavesPerBlock + wave_id_in_block();
@@ -939,8 +967,8 @@ __global__ __launch_bounds__(kBlock) void var_kernel_generic(const VarArgs a)
 {
     constexpr size_t F = 64 * V;
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.y;
-    if (tile_finished<V>(a.done, tile)) return;
+    const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
+    if (tile < 0) return;
     const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
     const int c_begin = wave * a.cols_per_wave;
     const int c_end = min(c_begin + a.cols_per_wave, a.n_cols);
@@ -1126,6 +1154,8 @@ struct StateArgs {
     int32_t iter;                       /* round whose syndrome `fail` holds; 0 = initialise */
     int32_t max_iter;
     int32_t freeze;                     /* early_term */
+    TailRef tail;
+    int32_t *__restrict__ running;      /* [max_iter + 2] or nullptr: running[iter] += frames still running */
 };
 
 /* isDones bookkeeping (decodeCL.c:48-49, checkDones :296-300): a frame whose
@@ -1134,7 +1164,11 @@ struct StateArgs {
 template <int V> __global__ void state_kernel(const StateArgs a)
 {
     constexpr int F = 64 * V;
-    const int tile = blockIdx.x;
+    int tile = blockIdx.x;
+    if (a.tail.state && a.iter > 0 && a.tail.state[0]) {      /* handed over: only the overflow tiles live */
+        if (tile >= a.tail.n_tiles) return;
+        tile = a.tail.base_tile + tile;
+    }
     const int lane = threadIdx.x;      /* 64 threads */
     int n_active = 0;
 #pragma unroll
@@ -1156,6 +1190,7 @@ template <int V> __global__ void state_kernel(const StateArgs a)
         n_active += __popcll(~d);
     }
     if (lane == 0 && n_active && a.active) atomicAdd(a.active, n_active);
+    if (lane == 0 && n_active && a.running) atomicAdd(&a.running[a.iter], n_active);
 }
 
 /* ---- tail compaction (early termination): when only a few frames of a large batch are still
@@ -1241,6 +1276,163 @@ __global__ void compact_child_state_kernel(uint64_t *__restrict__ done, int32_t 
     iters[jg] = max_iter;
     const uint64_t pad = __ballot(jg >= count);
     if (j == 0) done[ct] = pad;
+}
+
+/* ---- device-side tail: the same hand-over decided and carried out without the host ---------------
+ * tail_gather_kernel runs after the state update of a round.  Every block reads the number of
+ * frames still running after that round; unless 0 < running <= threshold (and at most a quarter
+ * of the batch) nothing happens.  Otherwise each block lists the running frames (the same list in
+ * every block: ascending mask word, ascending bit), and the blocks share the rows of Q, of the
+ * channel array and of the hard-bit masks: the running frames' values go to consecutive slots of
+ * the overflow tiles (same layout, same V).  The block that finishes last publishes the list,
+ * marks every batch tile finished and the overflow slots in use, and sets state[0]: the next
+ * launch's blocks follow it (tile_select).  tail_scatter_kernel brings bits, iteration counts and
+ * converged flags back before packing. */
+struct TailArgs {
+    int32_t *state;                     /* [0] handed, [1] count, [2] round, [3] ticket */
+    int32_t *map;                       /* [capacity] frame index of each overflow slot */
+    const int32_t *running;             /* [max_iter + 2] frames still running after round i */
+    uint64_t *done;                     /* [T + TO][V] */
+    int32_t *iters;                     /* [T + TO][F] */
+    void *Q;                            /* [T + TO][E][F] */
+    void *chan;                         /* [T + TO][N][F] */
+    uint64_t *hard;                     /* [T + TO][N][V] */
+    int64_t E;
+    int64_t frames;
+    int32_t N;
+    int32_t tiles;                      /* batch tiles in use by this call */
+    int32_t base_tile;                  /* first overflow tile */
+    int32_t capacity;                   /* overflow slots */
+    int32_t threshold;
+    int32_t iter;
+    int32_t max_iter;
+};
+
+constexpr int kTailMaxWords = 4096;     /* mask words a block can list: 262144 frames */
+
+template <int V, typename T>
+__global__ __launch_bounds__(kBlock) void tail_gather_kernel(const TailArgs a)
+{
+    constexpr int F = 64 * V;
+    __shared__ int32_t s_map[kCompactCapacity];
+    __shared__ int32_t s_scan[kBlock];
+    const int running = a.running[a.iter];
+    if (a.state[0] || running <= 0 || running > a.threshold || (int64_t)running * 4 > a.frames) return;   /* uniform */
+    const int words = a.tiles * V;
+    /* list the running frames: thread t owns words t, t + 256, ... (ascending); exclusive scan of the
+     * per-thread counts over consecutive word ranges keeps the order ascending in (word, bit) */
+    const int per = (words + kBlock - 1) / kBlock;
+    const int w0 = min((int)threadIdx.x * per, words), w1 = min(w0 + per, words);
+    int mine = 0;
+    for (int w = w0; w < w1; ++w) mine += __popcll(~a.done[w]);
+    s_scan[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < kBlock; off <<= 1) {
+        const int v = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0;
+        __syncthreads();
+        s_scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int slot = s_scan[threadIdx.x] - mine;
+    const int count = s_scan[kBlock - 1];
+    for (int w = w0; w < w1; ++w) {
+        uint64_t m = ~a.done[w];
+        const int tile = w / V, v = w % V;
+        while (m) {
+            const int l = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            if (slot < a.capacity) s_map[slot] = tile * F + l * V + v;      /* bit l of word v = frame V*l+v */
+            ++slot;
+        }
+    }
+    __syncthreads();
+    if (count > a.capacity || count != running) return;      /* cannot happen: both come from the same masks */
+    const int ctiles = (count + F - 1) / F;
+    /* rows of Q (E), of the channel array (N) and of the hard masks (N), dealt over the blocks */
+    const int64_t total_rows = a.E + 2 * (int64_t)a.N;
+    for (int64_t row = blockIdx.x; row < total_rows; row += gridDim.x) {
+        if (row < a.E + a.N) {
+            const bool isq = row < a.E;
+            const int64_t i = isq ? row : row - a.E, rows = isq ? a.E : a.N;
+            T *arr = static_cast<T *>(isq ? a.Q : a.chan);
+            for (int j = threadIdx.x; j < ctiles * F; j += kBlock) {
+                T val = (T)0;
+                if (j < count) {
+                    const int64_t f = s_map[j];
+                    val = arr[((f / F) * rows + i) * F + (f % F)];
+                }
+                arr[((size_t)(a.base_tile + j / F) * rows + i) * F + (j % F)] = val;
+            }
+        } else {
+            const int64_t n = row - a.E - a.N;
+            /* wave-wise: lane l of pass (ct, v) holds slot ct*F + V*l + v = bit l of word v */
+            const int lane = threadIdx.x & 63;
+            for (int unit = threadIdx.x >> 6; unit < ctiles * V; unit += kWavesPerBlock) {
+                const int ct = unit / V, v = unit % V;
+                const int j = ct * F + V * lane + v;
+                bool bit = false;
+                if (j < count) {
+                    const int64_t f = s_map[j];
+                    const int fi = (int)(f % F);
+                    bit = (a.hard[((f / F) * a.N + n) * V + fi % V] >> (fi / V)) & 1ull;
+                }
+                const uint64_t w = __ballot(bit);
+                if (lane == 0) a.hard[((size_t)(a.base_tile + ct) * a.N + n) * V + v] = w;
+            }
+        }
+    }
+    /* the last block to finish commits the hand-over */
+    __threadfence();
+    __shared__ int s_last;
+    if (threadIdx.x == 0) s_last = (atomicAdd(&a.state[3], 1) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int j = threadIdx.x; j < count; j += kBlock) a.map[j] = s_map[j];
+    for (int w = threadIdx.x; w < words; w += kBlock) a.done[w] = ~0ull;
+    const int TOv = (a.capacity / F) * V;
+    for (int w = threadIdx.x; w < TOv; w += kBlock) {
+        /* overflow word (ct, v): bit l in use iff slot ct*F + V*l + v < count */
+        const int ct = w / V, v = w % V;
+        uint64_t used = 0;
+        for (int l = 0; l < 64; ++l)
+            if (ct * F + V * l + v < count) used |= 1ull << l;
+        a.done[(size_t)a.base_tile * V + w] = ~used;
+    }
+    for (int j = threadIdx.x; j < a.capacity; j += kBlock) a.iters[(size_t)a.base_tile * F + j] = a.max_iter;
+    __threadfence();
+    if (threadIdx.x == 0) { a.state[1] = count; a.state[2] = a.iter; a.state[0] = 1; }
+}
+
+/* bits, iteration counts and converged flags of the handed-over frames back into the batch's tiles */
+template <int V> __global__ __launch_bounds__(kBlock) void tail_scatter_kernel(const TailArgs a)
+{
+    constexpr int F = 64 * V;
+    if (!a.state[0]) return;
+    const int count = a.state[1];
+    const int64_t n0 = (int64_t)blockIdx.x * kWavesPerBlock + wave_id_in_block();
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0) {
+        for (int j = threadIdx.x; j < count; j += kBlock) {
+            const int64_t f = a.map[j];
+            const int fi = (int)(f % F), oj = j % F;
+            a.iters[f] = a.iters[(size_t)a.base_tile * F + j];
+            const bool conv = (a.done[(size_t)(a.base_tile + j / F) * V + oj % V] >> (oj / V)) & 1ull;
+            /* the batch's word says "finished" for every frame since the hand-over: clear it for a
+             * frame that never reached a clean syndrome */
+            if (!conv) atomicAnd(reinterpret_cast<unsigned long long *>(a.done) + (f / F) * V + fi % V, ~(1ull << (fi / V)));
+        }
+    }
+    for (int64_t n = n0; n < a.N; n += (int64_t)gridDim.x * kWavesPerBlock) {
+        for (int j = lane; j < count; j += 64) {
+            const int64_t f = a.map[j];
+            const int fi = (int)(f % F), oj = j % F;
+            const bool bit = (a.hard[((size_t)(a.base_tile + j / F) * a.N + n) * V + oj % V] >> (oj / V)) & 1ull;
+            unsigned long long *word = reinterpret_cast<unsigned long long *>(a.hard) + ((f / F) * a.N + n) * V + fi % V;
+            if (bit) atomicOr(word, 1ull << (fi / V));
+            else atomicAnd(word, ~(1ull << (fi / V)));
+        }
+    }
 }
 
 struct PackArgs {

@@ -287,6 +287,11 @@ struct ldpc_decoder {
     DevBuf<int32_t> cmap;               /* [kCompactCapacity] frame indices handed to the child */
     int compact_threshold = ldpc::kCompactCapacity;   /* cfg.tune_compact: 0 = off, else hand over when <= this many frames run */
     bool is_child = false;
+    /* device-side tail (flood_kernels.hpp: TailRef, tail_gather_kernel): TO overflow tiles follow the T
+     * tiles of max_batch in every array (TA = T + TO allocated) */
+    bool tail_enabled = false;
+    int TO = 0, TA = 0;
+    DevBuf<int32_t> tail_state, tail_map, running;
 
     bool timing = false;                /* the call being enqueued is timed */
     int timing_every = 0;               /* 0 off, k: every k-th device call is timed */
@@ -434,11 +439,21 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
     const int max_iter = d->cfg.max_iter;
     const int rounds = d->tap_iter ? std::min(d->tap_iter, max_iter) : max_iter;
     const bool freeze = d->cfg.early_term != 0;
-    const size_t slot = (size_t)d->T * V;   /* words per fail slot */
+    const size_t slot = (size_t)d->TA * V;  /* words per fail slot */
 
     const bool resume = start_round > 1;    /* a child taking over running frames: their state is in place */
     HIP_TRY(hipMemsetAsync(d->failw.p, 0, d->failw.n * sizeof(uint64_t), s));
     HIP_TRY(hipMemsetAsync(d->summary.p, 0, 2 * sizeof(int32_t), s));
+    /* device-side tail: only when the call has clearly more tiles than the overflow area */
+    const bool use_tail = d->tail_enabled && freeze && !resume && !d->tap_iter && tiles >= 4 * d->TO;
+    const TailRef tr{use_tail ? d->tail_state.p : nullptr, d->T, d->TO};
+    TailArgs ta{};
+    if (use_tail) {
+        HIP_TRY(hipMemsetAsync(d->tail_state.p, 0, 4 * sizeof(int32_t), s));
+        HIP_TRY(hipMemsetAsync(d->running.p, 0, d->running.n * sizeof(int32_t), s));
+        ta = TailArgs{d->tail_state.p, d->tail_map.p, d->running.p, d->done.p, d->iters.p, d->Q.p, d->chan.p, d->hard.p,
+                      d->E, frames, d->N, tiles, d->T, d->TO * F, std::min(d->compact_threshold, d->TO * F), 0, max_iter};
+    }
 
     if (!resume) {
         HIP_TRY(span_begin(d, s, 3));
@@ -447,7 +462,8 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
         dim3 grid((d->N + kInitCols - 1) / kInitCols, tiles);
         d->init_fn<<<grid, kBlock, 0, s>>>(a);
         StateArgs st{d->done.p, nullptr, d->iters.p, nullptr, frames, 0, max_iter, freeze ? 1 : 0};
-        state_kernel<V><<<tiles, 64, 0, s>>>(st);
+        /* overflow tiles (and unused tiles in between) are born finished: frames beyond `frames` */
+        state_kernel<V><<<use_tail ? d->TA : tiles, 64, 0, s>>>(st);
         HIP_TRY(span_end(d, s));
     }
 
@@ -465,7 +481,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
                                msz * ((int64_t)rc.degree * rc.count + rc.linked +
                                       ((int64_t)rc.degree * rc.count - 2 * rc.linked) +
                                       (it < max_iter ? 2 * rc.linked : 0) + 2 * d->extra_edges) * frames));
-            CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree};
+            CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree, tr};
             LinkArgs lk{rc.link_col.p, rc.link_pos.p, d->chan.p, d->Q.p, d->hard.p, d->N,
                         (it < max_iter) ? 1 : 0, d->tap_iter ? 1 : 0, d->extra_e0.p, d->extra_deg.p, d->n_extra, 0};
             a.rows_per_wave = d->link_rpw;
@@ -480,14 +496,14 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             int64_t edges = 0;
             for (int i : g.members) edges += (int64_t)d->row_classes[i].degree * d->row_classes[i].count;
             HIP_TRY(span_begin(d, s, 5, g.hi, 2 * msz * edges * frames, -1, g.lo));
-            CheckArgs a{d->Q.p, d->R.p, nullptr, d->done.p, d->E, 0, d->tune_rpw ? d->tune_rpw : 2, 0};
+            CheckArgs a{d->Q.p, d->R.p, nullptr, d->done.p, d->E, 0, d->tune_rpw ? d->tune_rpw : 2, 0, tr};
             d->check_group_fn[g.bucket]<<<dim3(g.blocks, tiles), kBlock, 0, s>>>(a, g.table.p, (int)g.members.size());
             HIP_TRY(span_end(d, s));
         }
         for (int ci : d->check_solo) {
             RowClass &rc = d->row_classes[ci];
             HIP_TRY(span_begin(d, s, 0, rc.degree, 2 * msz * rc.degree * rc.count * frames));
-            CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree};
+            CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree, tr};
             const int slotk = rc.degree <= d->max_check_unrolled ? rc.degree : 0;
             const bool narrow = slotk && (!d->tune_check_wide || rc.degree > kMaxUnrolledDegree);
             const int rpw = d->tune_rpw ? d->tune_rpw : (narrow ? 2 : 1);
@@ -504,7 +520,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             for (int i : g.members) units += (int64_t)((wq ? 2 : 1) * d->col_classes[i].degree + 1) * d->col_classes[i].count;
             HIP_TRY(span_begin(d, s, 6, g.hi, msz * units * frames, -1, g.lo));
             VarArgs a{d->R.p, d->Q.p, d->chan.p, d->hard.p, d->done.p, nullptr, nullptr,
-                      d->E, d->N, 0, d->tune_cpw ? d->tune_cpw : 1, wq, 0};
+                      d->E, d->N, 0, d->tune_cpw ? d->tune_cpw : 1, wq, 0, tr};
             d->var_group_fn[g.bucket]<<<dim3(g.blocks, tiles), kBlock, 0, s>>>(a, g.table.p, (int)g.members.size());
             HIP_TRY(span_end(d, s));
         }
@@ -512,7 +528,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             ColClass &cc = d->col_classes[ci];
             HIP_TRY(span_begin(d, s, 1, cc.degree, msz * ((wq ? 2 : 1) * cc.degree + 1) * cc.count * frames));
             VarArgs a{d->R.p, d->Q.p, d->chan.p, d->hard.p, d->done.p, cc.col.p, cc.edge.p,
-                      d->E, d->N, cc.count, 1, wq, cc.degree};
+                      d->E, d->N, cc.count, 1, wq, cc.degree, tr};
             const int cpw = d->tune_cpw ? d->tune_cpw : 1;
             a.cols_per_wave = cpw;
             const int slotk = cc.degree <= kMaxUnrolledDegree ? cc.degree : 0;
@@ -528,10 +544,10 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             uint64_t *fw = d->failw.p + (size_t)it * slot;
             const int rbk = (d->M + kBlock - 1) / kBlock;
             SyndromeArgs sa{d->row_ptr.p, d->edge_col.p, d->hard.p, fw, d->done.p, d->M, d->N,
-                            d->tune_syn_xcd ? tiles : 0, rbk};
+                            d->tune_syn_xcd ? tiles : 0, rbk, tr};
             dim3 sgrid = d->tune_syn_xcd ? dim3(8 * rbk * ((tiles + 7) / 8)) : dim3(rbk, tiles);
             syndrome_kernel<V><<<sgrid, kBlock, 0, s>>>(sa);
-            StateArgs st{d->done.p, fw, d->iters.p, nullptr, frames, it, max_iter, 1};
+            StateArgs st{d->done.p, fw, d->iters.p, nullptr, frames, it, max_iter, 1, tr, use_tail ? d->running.p : nullptr};
             const bool poll = freeze && it < rounds && d->cfg.poll_interval > 0 && !d->suppress_poll &&
                               (it % d->cfg.poll_interval) == 0;
             if (poll) {
@@ -539,6 +555,14 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
                 st.active = d->active.p;
             }
             state_kernel<V><<<tiles, 64, 0, s>>>(st);
+            if (use_tail && it < rounds) {
+                /* hand the last running frames over to the overflow tiles if their number has fallen
+                 * below the threshold after this round (decided by the kernel; usually it just returns) */
+                ta.iter = it;
+                const unsigned tg = (unsigned)std::min<int64_t>(1024, d->E + 2 * (int64_t)d->N);
+                if (d->msg_size == 2) tail_gather_kernel<V, _Float16><<<tg, kBlock, 0, s>>>(ta);
+                else tail_gather_kernel<V, float><<<tg, kBlock, 0, s>>>(ta);
+            }
             HIP_TRY(span_end(d, s));
             if (poll) {
                 HIP_TRY(hipMemcpyAsync(d->h_active, d->active.p, sizeof(int32_t),
@@ -559,6 +583,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
     if (resume) return LDPC_OK;             /* the parent packs */
 
     HIP_TRY(span_begin(d, s, 3));
+    if (use_tail) tail_scatter_kernel<V><<<2048, kBlock, 0, s>>>(ta);
     {
         PackArgs pa{d->hard.p, out_dev, d->iters.p, iters_dev, frames, out_bytes, d->N, d->cfg.K,
                     d->cfg.pack_mode};
@@ -919,10 +944,18 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     HIP_TRY(d->edge_col.upload(g->cols));
     HIP_TRY(d->col_ptr.upload(g->col_ptr));
     HIP_TRY(d->col_edge.upload(g->col_edge));
-    const size_t TF = (size_t)d->T * d->F;
-    HIP_TRY(d->hard.alloc((size_t)d->T * d->N * d->V));
-    HIP_TRY(d->failw.alloc((size_t)(cfg->max_iter + 2) * d->T * d->V));
-    HIP_TRY(d->done.alloc((size_t)d->T * d->V));
+    /* Device-side tail: for asynchronous callers (poll_interval == 0) of the streaming flooding kernels
+     * with early termination, when the batch has clearly more tiles than the overflow area.
+     * LDPC_TUNE_OFF(LDPC_TUNE_DEVICE_TAIL) switches it off. */
+    d->TO = (ldpc::kCompactCapacity + d->F - 1) / d->F;
+    d->tail_enabled = cfg->early_term && cfg->poll_interval == 0 && ldpc::tune_pick(tune.device_tail, true) &&
+                      (cfg->algo == LDPC_ALGO_SP || cfg->algo == LDPC_ALGO_MS) && d->T >= 4 * d->TO && !t_creating_child;
+    if (!d->tail_enabled) d->TO = 0;
+    d->TA = d->T + d->TO;
+    const size_t TF = (size_t)d->TA * d->F;
+    HIP_TRY(d->hard.alloc((size_t)d->TA * d->N * d->V));
+    HIP_TRY(d->failw.alloc((size_t)(cfg->max_iter + 2) * d->TA * d->V));
+    HIP_TRY(d->done.alloc((size_t)d->TA * d->V));
     HIP_TRY(d->iters.alloc(TF));
     HIP_TRY(d->active.alloc(1));
     HIP_TRY(d->summary.alloc(2));
@@ -1001,6 +1034,11 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
         if (!d->use_fused) {
             int rc = setup_flooding(d, g, TF);
             if (rc) return rc;
+            if (d->tail_enabled) {
+                HIP_TRY(d->tail_state.alloc(4));
+                HIP_TRY(d->tail_map.alloc((size_t)d->TO * d->F));
+                HIP_TRY(d->running.alloc((size_t)cfg->max_iter + 2));
+            }
             /* tail compaction: with host polling on, the last <= 512 running frames of a batch of several
              * tiles are finished by a small (8 x 64 frames) child decoder (cfg.tune_compact = -1: off, n: threshold) */
             if (tune.compact) d->compact_threshold = tune.compact < 0 ? 0 : std::min(ldpc::kCompactCapacity, tune.compact);

@@ -628,3 +628,45 @@ def test_tail_compaction_of_running_frames(built, algo, f16):
                 assert st["frames_converged"] == n_conv, (compact, fpl)     # done flags scattered back by the child
                 assert st["iterations_launched"] == 30
             dec.close()
+
+
+@pytest.mark.parametrize("algo,f16", [("sp", False), ("ms", False), ("ms", True)])
+def test_device_side_tail_for_asynchronous_callers(built, algo, f16):
+    """Early termination WITHOUT host polling (ldpc_decode_device returns at once, all rounds are
+    enqueued): once few enough frames still run, a kernel moves them into the overflow tiles and
+    every later launch works on those alone -- decided on the device.  Bits, iteration counts and
+    the converged count must be the oracle's; with the feature off and with a threshold that is
+    reached late the same."""
+    import torch
+    g, og, K, M, z = _graph(codes.RATE_1_2, 1152)
+    B = 2100                                                      # 9 tiles of 256 / 33 of 64
+    rng = np.random.default_rng(43)
+    y = channel.awgn_frames(1152, 0, B, 0.62, seed=44)            # most frames converge within a few rounds ...
+    hard = rng.choice(B, 90, replace=False)
+    y[hard] = channel.awgn_frames(1152, 7000, 90, 1.05, seed=45)  # ... some scattered ones (almost) never do
+    want = oracle.decode(og, y, algo, max_iter=30, msg_f16=f16)
+    rows, cols = codes.wimax_edges(codes.RATE_1_2, 1152)
+    n_conv = int(converged_frames(rows, cols, M, want["hard"]).sum())
+    assert (want["iters"] == 30).sum() >= 65 and (want["iters"] < 12).sum() > B - 120
+    yd = torch.from_numpy(y).cuda()
+    nb = L.out_bytes(K, B)
+    for tune in ({}, {"compact": 100}, {"device_tail": False}):
+        for fpl in (1, 2, 4):
+            dec = L.Decoder(g, K, max_batch=B, algo=algo, max_iter=30, poll_interval=0, frames_per_lane=fpl,
+                            msg_dtype="f16" if f16 else "f32", tune=tune)
+            for _ in range(2):
+                out = torch.full((nb,), 0xEE, dtype=torch.uint8, device="cuda")
+                it = torch.zeros(B, dtype=torch.int32, device="cuda")
+                dec.decode_device(yd.data_ptr(), B, out.data_ptr(), nb, it.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                assert np.array_equal(out.cpu().numpy(), want["out"]), (tune, fpl)
+                assert np.array_equal(it.cpu().numpy(), want["iters"]), (tune, fpl)
+                st = dec.stats()
+                assert st["frames_converged"] == n_conv and st["batch_time"] == 30, (tune, fpl)
+                assert st["iterations_launched"] == 30              # asynchronous: every round is enqueued
+            dec.close()
+    # a batch too small for the overflow area simply runs without it
+    dec = L.Decoder(g, K, max_batch=300, algo=algo, max_iter=30, msg_dtype="f16" if f16 else "f32")
+    o2, i2 = dec.decode(y[:300])
+    assert np.array_equal(i2, want["iters"][:300]) and np.array_equal(o2, want["out"][:300 * K // 8])
+    dec.close()
