@@ -274,7 +274,8 @@ struct ldpc_decoder {
         DevBuf<int32_t> iters;
         uint8_t *h_out = nullptr;       /* pinned: D2H completes without blocking the host */
         int32_t *h_iters = nullptr;
-        uint8_t *h_head = nullptr;      /* pinned page: a group's bytes before its first page boundary */
+        uint8_t *h_head = nullptr;      /* two pinned pages: a group's bytes before its first page boundary and,
+                                           for the last group, after its last one */
         hipEvent_t h2d_done = nullptr, all_done = nullptr;
         bool busy = false;
         int64_t off = 0, n = 0, dst = 0, copy_bytes = 0;
@@ -1211,7 +1212,7 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
         HIP_TRY(sl.iters.alloc((size_t)B));
         HIP_TRY(hipHostMalloc((void **)&sl.h_out, (size_t)stage_out, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc((void **)&sl.h_iters, (size_t)B * sizeof(int32_t), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void **)&sl.h_head, 4096, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&sl.h_head, 2 * 4096, hipHostMallocDefault));
         HIP_TRY(hipEventCreateWithFlags(&sl.h2d_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sl.all_done, hipEventDisableTiming));
     }
@@ -1228,13 +1229,17 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
      * 140 ms decode instead of 19 ms), so from the second group on the caller's pages are page-locked
      * for the duration of the call: a true DMA that runs beside the previous group's kernels.
      * Group k >= 1 owns the block from its first page boundary up to the next group's first page
-     * boundary: blocks are page-disjoint (two registrations never share a page, neither within this
-     * call nor with the neighbouring frame range of another device's thread), each is registered
-     * just before its copy -- i.e. while the previous group decodes -- and all are released only
-     * after both streams have drained.  The few bytes of a group that lie before its first page
-     * boundary are read by the CPU into a pinned scratch page.  Group 0 is copied as it is: nothing
-     * of this call runs yet that it could overlap with.  A block that cannot be registered (already
-     * page-locked by the caller, or by another call decoding the same buffer) is copied pageable. */
+     * boundary -- the last group up to its LAST page boundary: blocks are whole pages inside this
+     * call's own byte range and page-disjoint.  No registered page is ever shared with memory that
+     * anybody copies as pageable (this call's group 0, or group 0 of the neighbouring frame range in
+     * another device's thread: the runtime would take such a source for pinned memory and read past
+     * the registered block -- a GPU memory fault, seen once).  Each block is registered just before
+     * its copy -- i.e. while the previous group decodes -- and all are released only after both
+     * streams have drained.  The bytes of a group before its first page boundary (and after the last
+     * group's last one) are read by the CPU into pinned scratch pages.  Group 0 is copied as it is:
+     * nothing of this call runs yet that it could overlap with.  A block that cannot be registered
+     * (already page-locked by the caller, or by another call decoding the same buffer) is copied
+     * pageable. */
     std::vector<void *> pinned;
     int rc = LDPC_OK;
 #ifdef LDPC_TRACE_HOST
@@ -1257,18 +1262,24 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
         const size_t bytes = (size_t)n * d->N * sizeof(float);
         const uintptr_t s0 = (uintptr_t)src, s1 = s0 + bytes, b0 = (s0 + 4095) & ~(uintptr_t)4095;
         hipError_t e = hipSuccess;
-        if (kk >= 1 && b0 < s1) {
-            const uintptr_t b1 = kk + 1 < ngroups ? ((s1 + 4095) & ~(uintptr_t)4095) : s1;
+        const bool last = kk + 1 == ngroups;
+        const uintptr_t b1 = last ? (s1 & ~(uintptr_t)4095) : ((s1 + 4095) & ~(uintptr_t)4095);   /* end of the block */
+        if (kk >= 1 && b0 < b1) {
             if (hipHostRegister((void *)b0, (size_t)(b1 - b0), hipHostRegisterPortable) == hipSuccess) pinned.push_back((void *)b0);
             else (void)hipGetLastError();
-            const size_t head = (size_t)(b0 - s0);
+            const uintptr_t body_end = last ? b1 : s1;               /* the copy stops at the group's data */
+            const size_t head = (size_t)(b0 - s0), body = (size_t)(body_end - b0), tail = (size_t)(s1 - body_end);
+            uint8_t *dst = reinterpret_cast<uint8_t *>(sl.llr.p);
             if (head) {
                 memcpy(sl.h_head, src, head);
-                e = hipMemcpyAsync(sl.llr.p, sl.h_head, head, hipMemcpyHostToDevice, d->copy_stream);
+                e = hipMemcpyAsync(dst, sl.h_head, head, hipMemcpyHostToDevice, d->copy_stream);
             }
             if (e == hipSuccess)
-                e = hipMemcpyAsync(reinterpret_cast<uint8_t *>(sl.llr.p) + head, (const void *)b0, bytes - head,
-                                   hipMemcpyHostToDevice, d->copy_stream);
+                e = hipMemcpyAsync(dst + head, (const void *)b0, body, hipMemcpyHostToDevice, d->copy_stream);
+            if (e == hipSuccess && tail) {
+                memcpy(sl.h_head + 4096, (const void *)body_end, tail);
+                e = hipMemcpyAsync(dst + head + body, sl.h_head + 4096, tail, hipMemcpyHostToDevice, d->copy_stream);
+            }
         } else {
             e = hipMemcpyAsync(sl.llr.p, src, bytes, hipMemcpyHostToDevice, d->copy_stream);
         }
