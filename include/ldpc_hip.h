@@ -51,16 +51,24 @@ enum ldpc_status {
 /* decodeType of the reference (MyLdpc.h:37-39) maps as:
  *   DecodeSP                 -> LDPC_ALGO_SP       (decodeCL.c:3-108)
  *   DecodeMS, DecodeCPU      -> LDPC_ALGO_MS       (decodeCL.c:113-186, MyLdpc.cpp:684-784)
- *   DecodeTDMP, DecodeTDMPCL -> LDPC_ALGO_LAYERED  (semantics of decodeCL.c:307-426)
+ *   DecodeTDMPCL             -> LDPC_ALGO_LAYERED  (the fused kernel, decodeCL.c:307-426)
+ *   DecodeTDMP               -> LDPC_ALGO_LAYERED_HOST where the reference's host-layered path is
+ *                               well defined (all rows of H of one weight), else LDPC_ALGO_LAYERED
  *   DecodeMSCL               -> LDPC_ALGO_MS_FUSED (decodeCL.c:432-567) */
 enum ldpc_algo {
     LDPC_ALGO_SP = 0,      /* flooding sum-product, probability domain, fp32     */
     LDPC_ALGO_MS = 1,      /* flooding min-sum, fp32                             */
     LDPC_ALGO_LAYERED = 2, /* layered (TDMP) min-sum                             */
-    LDPC_ALGO_MS_FUSED = 3 /* flooding min-sum with the arithmetic of the fused kernel
+    LDPC_ALGO_MS_FUSED = 3,/* flooding min-sum with the arithmetic of the fused kernel
                               decodeOnceMS (DecodeMSCL, decodeCL.c:432-567): short
                               quasi-cyclic codes only, whole decode in LDS; the reference
                               hard-codes max_iter = 120 there                            */
+    LDPC_ALGO_LAYERED_HOST = 4 /* layered min-sum as the reference's HOST drives it (DecodeTDMP,
+                              MyLdpc.cpp:889-976 over decodeCL.c:203-300): check node of the MS
+                              kernel chain, three-way hard decision once per iteration.  The
+                              reference mis-sizes its layers unless every row of H has the same
+                              weight (MyLdpc.cpp:907,958): any other H is LDPC_ERR_UNSUPPORTED.
+                              fp32, one launch per layer                                    */
 };
 
 enum ldpc_msg_dtype { LDPC_MSG_F32 = 0, LDPC_MSG_F16 = 1 };

@@ -11,10 +11,11 @@ import numpy as np
 from . import _lib
 from ._lib import DecoderConfig, DecodeStats, LdpcError  # noqa: F401
 
-ALGO_SP, ALGO_MS, ALGO_LAYERED, ALGO_MS_FUSED = 0, 1, 2, 3
+ALGO_SP, ALGO_MS, ALGO_LAYERED, ALGO_MS_FUSED, ALGO_LAYERED_HOST = 0, 1, 2, 3, 4
 MSG_F32, MSG_F16 = 0, 1
 PACK_BYTES, PACK_BITS = 0, 1
-ALGOS = {"sp": ALGO_SP, "ms": ALGO_MS, "layered": ALGO_LAYERED, "ms_fused": ALGO_MS_FUSED}
+ALGOS = {"sp": ALGO_SP, "ms": ALGO_MS, "layered": ALGO_LAYERED, "ms_fused": ALGO_MS_FUSED,
+         "layered_host": ALGO_LAYERED_HOST}
 
 # two-bit fields of ldpc_decoder_config.tune_flags (enum ldpc_tune_field): True forces on, False off
 TUNE_FIELDS = {"fused": 0, "ldsp": 2, "ldsp_ext": 4, "ldsp_pack": 6, "link_narrow": 8, "check_wide": 10,

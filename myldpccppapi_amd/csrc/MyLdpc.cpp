@@ -250,6 +250,17 @@ int Coder::addDecodeType(enum decodeType deType)
     cfg.layer_rows = z;
     cfg.algo = (deType == DecodeSP) ? LDPC_ALGO_SP : (deType == DecodeMS) ? LDPC_ALGO_MS
                : (deType == DecodeMSCL) ? LDPC_ALGO_MS_FUSED : LDPC_ALGO_LAYERED;
+    if (deType == DecodeTDMP) {
+        /* The reference's host-layered path (MyLdpc.cpp:889-976) sizes layer l as
+         * hRowRange[l + z] - hRowRange[l] (:907, :958): right only when all rows of H have one weight
+         * (rates 2/3A and 5/6).  There DecodeTDMP follows it operation for operation
+         * (LDPC_ALGO_LAYERED_HOST); for the other seeds the reference's result is not a decode of H,
+         * and DecodeTDMP runs the layered schedule with the fused kernel's semantics instead. */
+        bool uniform = true;
+        for (int m = 1; m < ldpcM && uniform; ++m)
+            uniform = (rowRange[m + 1] - rowRange[m]) == (rowRange[1] - rowRange[0]);
+        if (uniform) cfg.algo = LDPC_ALGO_LAYERED_HOST;
+    }
     if (deType == DecodeMSCL) cfg.max_iter = 120;      /* hard-coded in the reference kernel, decodeCL.c:479 */
     ldpc_decoder *d = nullptr;
     int rc = makeDecoder(cfg, &d);

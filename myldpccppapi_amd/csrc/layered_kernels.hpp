@@ -53,7 +53,12 @@ __device__ __forceinline__ float cl_sign(float x)
     return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : (x == 0.0f ? x : 0.0f));
 }
 
-template <int D, int V>
+/* HOST = false: the arithmetic of the fused kernel decodeOnceTDMP (above).
+ * HOST = true: the reference's host-layered path, Coder::decodeOnceTDMP (MyLdpc.cpp:889-976) over
+ * refreshQTDMP / refreshRTDMP / refreshPostPTDMP (decodeCL.c:228-259, 283-290): q_k = P - R_k, the
+ * check node of the MS kernel chain (sign = XOR of `< 0`, magnitude = fmin chain from 1000 ==
+ * check_ms), P = q_k + R_k; the hard decision is taken once per iteration by layered_hard_kernel. */
+template <int D, int V, bool HOST = false>
 __global__ __launch_bounds__(kBlock) void layer_kernel(const LayerArgs a)
 {
     constexpr size_t F = 64 * V;
@@ -80,6 +85,21 @@ __global__ __launch_bounds__(kBlock) void layer_kernel(const LayerArgs a)
         for (int k = 0; k < D; ++k) {
             vload<V>(m[k], Rt + (size_t)(e0 + k) * F);
             vload<V>(p[k], Pt + (size_t)col[k] * F);
+        }
+        if (HOST) {
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+#pragma unroll
+                for (int v = 0; v < V; ++v) p[k][v] = p[k][v] - m[k][v];      /* refreshQTDMP */
+            check_ms<D, V>(p, m);                                                 /* refreshRTDMP */
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) p[k][v] = p[k][v] + m[k][v];      /* refreshPostPTDMP */
+                vstore<V>(Rt + (size_t)(e0 + k) * F, m[k]);
+                vstore<V>(Pt + (size_t)col[k] * F, p[k]);
+            }
+            continue;
         }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
@@ -187,12 +207,38 @@ __global__ __launch_bounds__(kBlock) void layer_kernel_generic(const LayerArgs a
     }
 }
 
+/* hardDecisionTDMP, decodeCL.c:261-280, after the last layer of an iteration: P > 0 -> 0, P < 0 -> 1,
+ * otherwise (0, NaN) the bit stays; frozen frames keep theirs.  One wave per column. */
+template <int V>
+__global__ __launch_bounds__(kBlock) void layered_hard_kernel(const float *__restrict__ P, uint64_t *hard,
+                                                              const uint64_t *__restrict__ done, int32_t N)
+{
+    constexpr size_t F = 64 * V;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.y;
+    if (tile_finished<V>(done, tile)) return;
+    const int n = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
+    if (n >= N) return;
+    float p[V];
+    vload<V>(p, P + ((size_t)tile * N + n) * F + (size_t)lane * V);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const uint64_t old = hard[((size_t)tile * N + n) * V + v];
+        const bool oldb = (old >> lane) & 1ull;
+        const bool b = (p[v] > 0.0f) ? false : ((p[v] < 0.0f) ? true : oldb);
+        const uint64_t w = __ballot(b);
+        const uint64_t frozen = done[(size_t)tile * V + v];
+        if (lane == 0) hard[((size_t)tile * N + n) * V + v] = (old & frozen) | (w & ~frozen);
+    }
+}
+
 struct LayeredInitArgs {
     const float *__restrict__ llr;  /* [frames][N] */
     float *__restrict__ P;          /* [T][N][F] */
     uint64_t *__restrict__ hard;    /* [T][N][V] */
     int64_t frames;
     int32_t N;
+    int32_t zero_bits;              /* host-layered path: bits start at 0 (the reference: undefined) */
 };
 
 /* lP = postCode (decodeCL.c:331-334), transposed into the tile layout; bits = y < 0. */
@@ -226,7 +272,7 @@ __global__ __launch_bounds__(kBlock) void layered_init_kernel(const LayeredInitA
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             const uint64_t w = __ballot(y[v] < 0.0f);
-            if (lane == 0) a.hard[((size_t)tile * a.N + n) * V + v] = w;
+            if (lane == 0) a.hard[((size_t)tile * a.N + n) * V + v] = a.zero_bits ? 0ull : w;
         }
     }
 }
@@ -242,6 +288,7 @@ struct LayeredPlan {
     int32_t M = 0, N = 0, layer_rows = 0;
     int64_t E = 0;
     int T = 0, V = 1;
+    int host_arith = 0;             /* 1: LDPC_ALGO_LAYERED_HOST (layer_kernel<.., HOST = true>) */
     float *P = nullptr, *R = nullptr;
     std::vector<LayerGroup> groups; /* ordered by layer */
 };
@@ -308,11 +355,11 @@ struct LayeredRun {
 };
 
 using LayerFn = void (*)(const LayerArgs);
-template <int V, int D> struct LayerTable {
-    static void fill(LayerFn *t) { t[D] = layer_kernel<D, V>; LayerTable<V, D - 1>::fill(t); }
+template <int V, int D, bool HOST = false> struct LayerTable {
+    static void fill(LayerFn *t) { t[D] = layer_kernel<D, V, HOST>; LayerTable<V, D - 1, HOST>::fill(t); }
 };
-template <int V> struct LayerTable<V, 0> {
-    static void fill(LayerFn *t) { t[0] = layer_kernel_generic<V>; }
+template <int V, bool HOST> struct LayerTable<V, 0, HOST> {
+    static void fill(LayerFn *t) { t[0] = HOST ? nullptr : layer_kernel_generic<V>; }
 };
 
 constexpr int kMaxUnrolledLayerDegree = 24;
@@ -336,14 +383,15 @@ inline hipError_t layered_run_v(LayeredPlan *pl, const LayeredRun &r, hipStream_
     const int tiles = (int)((r.frames + F - 1) / F);
     const size_t slot = (size_t)pl->T * V;
     LayerFn table[kMaxUnrolledLayerDegree + 1];
-    LayerTable<V, kMaxUnrolledLayerDegree>::fill(table);
+    if (pl->host_arith) LayerTable<V, kMaxUnrolledLayerDegree, true>::fill(table);
+    else LayerTable<V, kMaxUnrolledLayerDegree>::fill(table);
     const int rounds = r.tap_iter ? (r.tap_iter < r.max_iter ? r.tap_iter : r.max_iter) : r.max_iter;
     hipError_t e;
     if ((e = hipMemsetAsync(r.failw, 0, (size_t)(r.max_iter + 2) * slot * sizeof(uint64_t), s))) return e;
     if ((e = hipMemsetAsync(r.summary, 0, 2 * sizeof(int32_t), s))) return e;
     if ((e = hipMemsetAsync(pl->R, 0, (size_t)tiles * F * (size_t)pl->E * sizeof(float), s))) return e;
     {
-        LayeredInitArgs ia{r.llr_dev, pl->P, r.hard, r.frames, pl->N};
+        LayeredInitArgs ia{r.llr_dev, pl->P, r.hard, r.frames, pl->N, pl->host_arith};
         dim3 grid((pl->N + kInitCols - 1) / kInitCols, tiles);
         layered_init_kernel<V><<<grid, kBlock, 0, s>>>(ia);
         StateArgs st{r.done, nullptr, r.iters, nullptr, r.frames, 0, r.max_iter, 1};
@@ -357,10 +405,15 @@ inline hipError_t layered_run_v(LayeredPlan *pl, const LayeredRun &r, hipStream_
             const int waves = (g.count + a.rows_per_wave - 1) / a.rows_per_wave;
             dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
             const int k = g.degree <= kMaxUnrolledLayerDegree ? g.degree : 0;
+            if (!table[k]) return hipErrorInvalidValue;      /* host arithmetic: unrolled degrees only */
             if (r.span_begin && (e = r.span_begin(r.span_ctx, s, 2, g.degree,
                                                   (int64_t)16 * g.degree * g.count * r.frames))) return e;
             table[k]<<<grid, kBlock, 0, s>>>(a);
             if (r.span_end && (e = r.span_end(r.span_ctx, s))) return e;
+        }
+        if (pl->host_arith) {
+            dim3 hgrid((pl->N + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
+            layered_hard_kernel<V><<<hgrid, kBlock, 0, s>>>(pl->P, r.hard, r.done, pl->N);
         }
         /* syndrome of this round's bits, freeze (decodeCL.c:393-410) */
         if (!r.early_term && it != rounds) continue;

@@ -897,8 +897,16 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     if (cfg->max_batch <= 0) return fail(LDPC_ERR_ARG, "max_batch must be positive");
     if (cfg->max_iter <= 0 || cfg->max_iter > 100000) return fail(LDPC_ERR_ARG, "max_iter out of range");
     if (cfg->algo != LDPC_ALGO_SP && cfg->algo != LDPC_ALGO_MS && cfg->algo != LDPC_ALGO_LAYERED &&
-        cfg->algo != LDPC_ALGO_MS_FUSED)
+        cfg->algo != LDPC_ALGO_MS_FUSED && cfg->algo != LDPC_ALGO_LAYERED_HOST)
         return fail(LDPC_ERR_ARG, "unknown algo %d", cfg->algo);
+    if (cfg->algo == LDPC_ALGO_LAYERED_HOST) {
+        for (int32_t m = 1; m < g->M; ++m)
+            if (g->row_ptr[m + 1] - g->row_ptr[m] != g->row_ptr[1] - g->row_ptr[0])
+                return fail(LDPC_ERR_UNSUPPORTED, "LAYERED_HOST follows the reference's host-layered path, which sizes its "
+                            "layers correctly only when every row of H has the same weight (MyLdpc.cpp:907,958)");
+        if (g->max_row_deg > ldpc::kMaxUnrolledLayerDegree)
+            return fail(LDPC_ERR_UNSUPPORTED, "LAYERED_HOST: row weight %d > %d", g->max_row_deg, ldpc::kMaxUnrolledLayerDegree);
+    }
     if (cfg->pack_mode != LDPC_PACK_BYTES && cfg->pack_mode != LDPC_PACK_BITS)
         return fail(LDPC_ERR_ARG, "unknown pack_mode %d", cfg->pack_mode);
     if (cfg->frames_per_lane != 0 && cfg->frames_per_lane != 1 && cfg->frames_per_lane != 2 &&
@@ -979,6 +987,12 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
                             "posteriors fit in LDS");
         }
         d->use_fused = true;
+    } else if (cfg->algo == LDPC_ALGO_LAYERED_HOST) {
+        d->layered.host_arith = 1;
+        int rc = ldpc::layered_plan_create(&d->layered, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows, d->T, d->V);
+        if (rc == -1) return fail(LDPC_ERR_ARG, "layer_rows=%d must divide M=%d and rows of a layer "
+                                  "must not share a column", cfg->layer_rows, g->M);
+        if (rc) return fail(LDPC_ERR_HIP, "layered plan allocation failed: %s", hipGetErrorString(hipGetLastError()));
     } else if (cfg->algo == LDPC_ALGO_LAYERED) {
         /* short quasi-cyclic codes decode entirely in LDS, one launch (fused_kernels.hpp);
          * LDPC_TUNE_OFF(LDPC_TUNE_FUSED) keeps the streaming kernels (same results, bit for bit) */
@@ -1162,7 +1176,7 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
                             : ldpc::fused_run(&d->fused, run, s, &d->last_iterations);
         if (e == hipSuccess) e = span_end(d, s);
         rc = (e == hipSuccess) ? LDPC_OK : fail(LDPC_ERR_HIP, "fused decode: %s", hipGetErrorString(e));
-    } else if (d->cfg.algo == LDPC_ALGO_LAYERED) {
+    } else if (d->cfg.algo == LDPC_ALGO_LAYERED || d->cfg.algo == LDPC_ALGO_LAYERED_HOST) {
         ldpc::LayeredRun run;
         run.span_begin = [](void *c, hipStream_t st, int kind, int deg, int64_t bytes) {
             return span_begin((ldpc_decoder *)c, st, kind, deg, bytes);
@@ -1462,8 +1476,8 @@ int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t ca
     HIP_TRY(hipEventSynchronize(d->ev_end));
     const char *phase_name[] = {"check_kernel", "var_kernel", "layer_kernel", "other",
                                 d->tune_link_narrow ? "check_link_narrow_kernel" : "check_link_kernel"};
-    static const char *algo_name_f32[] = {"sp", "ms", "layered", "ms_fused"};
-    static const char *algo_name_f16[] = {"sp16", "ms16", "layered16", "ms_fused16"};
+    static const char *algo_name_f32[] = {"sp", "ms", "layered", "ms_fused", "layered_host"};
+    static const char *algo_name_f16[] = {"sp16", "ms16", "layered16", "ms_fused16", "layered_host16"};
     const char **algo_name = d->msg_size == 2 ? algo_name_f16 : algo_name_f32;
     for (size_t i = 0; i < d->spans_used; ++i) {
         const TimedSpan &sp = d->spans[i];
@@ -1549,7 +1563,7 @@ int ldpc_decoder_dump(ldpc_decoder *d, int32_t which, float *host_out, int64_t c
         HIP_TRY(hipMemcpy(host_out, src, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
         return LDPC_OK;
     }
-    if (d->cfg.algo == LDPC_ALGO_LAYERED) {
+    if (d->cfg.algo == LDPC_ALGO_LAYERED || d->cfg.algo == LDPC_ALGO_LAYERED_HOST) {
         hipError_t e = ldpc::layered_dump(&d->layered, which, host_out, count, frames, d->hard.p,
                                           d->h_cols.data());
         if (e == hipErrorInvalidValue) return fail(LDPC_ERR_ARG, "bad `which`/count for layered dump");

@@ -59,6 +59,8 @@ def lib():
         L.oracle_decode_layered.restype = ctypes.c_int
         L.oracle_decode_layered.argtypes = common + [ctypes.c_int32, _f32p, ctypes.c_int64,
                                                      ctypes.c_int] + tail + [_u8p]
+        L.oracle_decode_layered_host.restype = ctypes.c_int
+        L.oracle_decode_layered_host.argtypes = common + [ctypes.c_int32, _f32p, ctypes.c_int64, ctypes.c_int] + tail
         L.oracle_decode_ms_fused.restype = ctypes.c_int
         L.oracle_decode_ms_fused.argtypes = common + [_f32p, ctypes.c_int64, ctypes.c_int] + tail + [_u8p]
         L.oracle_code_size.restype = ctypes.c_int64
@@ -113,7 +115,8 @@ def out_len(frames, K, pack_mode=0):
 
 
 def decode(g, y, algo, max_iter=40, llr_scale=8.0, pack_mode=0, layer_rows=0, tap_iter=0, msg_f16=False):
-    """Run one oracle decoder.  algo in {"ms", "sp", "layered"}.
+    """Run one oracle decoder.  algo in {"ms", "sp", "layered", "layered_host", "ms_fused"}.
+    "layered_host" = the reference's host-layered DecodeTDMP path (uniform row weight only).
 
     "ms_fused" = the arithmetic of the reference's fused flooding kernel (DecodeMSCL).
     Returns dict(out=bytes array, iters=int32[frames], hard=uint8[frames,N],
@@ -129,7 +132,7 @@ def decode(g, y, algo, max_iter=40, llr_scale=8.0, pack_mode=0, layer_rows=0, ta
     if tap_iter:
         ctaps = _Taps()
         ctaps.iter = tap_iter
-        names = ("r0", "r1", "q0", "q1") if algo == "sp" else (("r", "post") if algo in ("layered", "ms_fused") else ("r", "q", "post"))
+        names = ("r0", "r1", "q0", "q1") if algo == "sp" else (("r", "post") if algo in ("layered", "layered_host", "ms_fused") else ("r", "q", "post"))
         for nm in names:
             n = g.N if nm == "post" else g.E
             taps[nm] = np.full((frames, n), np.nan, np.float32)
@@ -145,6 +148,11 @@ def decode(g, y, algo, max_iter=40, llr_scale=8.0, pack_mode=0, layer_rows=0, ta
         undef = np.zeros(frames, np.uint8)
         rc = L.oracle_decode_layered(ctypes.byref(g._c), layer_rows, _p(y, _f32p), frames,
                                      max_iter, *tail, _p(undef, _u8p))
+    elif algo == "layered_host":
+        rc = L.oracle_decode_layered_host(ctypes.byref(g._c), layer_rows, _p(y, _f32p), frames, max_iter, *tail)
+        if rc == -3:
+            raise ValueError("layered_host: rows of different weight (the reference's host-layered path is "
+                             "only defined for uniform row weight, MyLdpc.cpp:907,958)")
     elif algo == "ms_fused":
         undef = np.zeros(frames, np.uint8)
         rc = L.oracle_decode_ms_fused(ctypes.byref(g._c), _p(y, _f32p), frames, max_iter, *tail,

@@ -407,6 +407,73 @@ int oracle_decode_layered(const oracle_graph *g, int32_t layer_rows, const float
     return 0;
 }
 
+/* ------------------------------------------ host-layered TDMP (DecodeTDMP) */
+
+int oracle_decode_layered_host(const oracle_graph *g, int32_t layer_rows, const float *y,
+                               int64_t frames, int max_iter, int pack_mode, uint8_t *out,
+                               int64_t out_bytes, int32_t *iters, uint8_t *hard_out,
+                               const oracle_taps *taps)
+{
+    const int64_t E = g->E;
+    const int32_t N = g->N, M = g->M;
+    if (layer_rows <= 0 || M % layer_rows) return -1;
+    /* MyLdpc.cpp:907,958: threadNum = hRowRange[blockRow + z] - hRowRange[blockRow] is layer
+     * blockRow's edge count only if every row has the same weight */
+    for (int32_t m = 1; m < M; ++m)
+        if (g->row_ptr[m + 1] - g->row_ptr[m] != g->row_ptr[1] - g->row_ptr[0]) return -3;
+    float *lP = (float *)malloc(sizeof(float) * (size_t)N);
+    float *lR = (float *)malloc(sizeof(float) * (size_t)E);
+    float *lQ = (float *)malloc(sizeof(float) * (size_t)E);
+    uint8_t *src = (uint8_t *)malloc((size_t)N);
+    if (!lP || !lR || !lQ || !src) return -2;
+    for (int64_t f = 0; f < frames; ++f) {
+        const float *yf = y + f * N;
+        int time = 0;
+        memcpy(lP, yf, sizeof(float) * (size_t)N);         /* decodeInitTDMP, decodeCL.c:213-216 */
+        for (int64_t e = 0; e < E; ++e) lR[e] = 0;         /* :219-220 */
+        memset(src, 0, (size_t)N);                         /* srcBool: undefined in the reference, 0 here */
+        while (1) {
+            /* layers in order; the rows of a layer touch disjoint columns, so taking them one
+             * after the other equals the reference's three launches per layer */
+            for (int32_t row = 0; row < M; ++row) {
+                const int32_t lo = g->row_ptr[row], hi = g->row_ptr[row + 1];
+                /* refreshQTDMP, decodeCL.c:283-290 (first pass: decodeInitTDMP's lQ = code, lR = 0,
+                 * :208-211 -- the same value, y - 0) */
+                for (int32_t p = lo; p < hi; ++p) lQ[p] = lP[g->cols[p]] - lR[p];
+                for (int32_t p = lo; p < hi; ++p) {        /* refreshRTDMP, :228-249 */
+                    int a = 0;
+                    float b = 1000;
+                    for (int32_t q = lo; q < hi; ++q) {
+                        if (q == p) continue;
+                        if (lQ[q] < 0) a ^= 1;
+                        b = fminf(b, fabsf(lQ[q]));
+                    }
+                    lR[p] = a ? -b : b;
+                }
+                for (int32_t p = lo; p < hi; ++p)          /* refreshPostPTDMP, :251-259 */
+                    lP[g->cols[p]] = lQ[p] + lR[p];
+            }
+            for (int32_t n = 0; n < N; ++n) {              /* hardDecisionTDMP, :261-280 */
+                if (lP[n] > 0) src[n] = 0;
+                else if (lP[n] < 0) src[n] = 1;
+            }
+            const int flag = syndrome_fails(g, src);       /* checkResult :88-108, checkDones :296-300 */
+            ++time;                                        /* MyLdpc.cpp:943 */
+            if (taps && taps->iter == time) {
+                tap_copy(taps->r, f, E, lR);
+                tap_copy(taps->post, f, N, lP);
+            }
+            if (!flag) break;                              /* :949-950 (per frame: isDones) */
+            if (time == max_iter) break;                   /* :951-952 */
+        }
+        if (iters) iters[f] = time;
+        if (hard_out) memcpy(hard_out + f * N, src, (size_t)N);
+        pack_frame(g, src, f, pack_mode, out, out_bytes);
+    }
+    free(lP); free(lR); free(lQ); free(src);
+    return 0;
+}
+
 /* --------------------------------------------- fused flooding min-sum (MSCL) */
 
 /* The arithmetic of the fused flooding kernel decodeOnceMS, decodeCL.c:432-567

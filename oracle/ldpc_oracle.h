@@ -107,6 +107,19 @@ int oracle_decode_layered(const oracle_graph *g, int32_t layer_rows, const float
                           int64_t out_bytes, int32_t *iters, uint8_t *hard_out,
                           const oracle_taps *taps, uint8_t *undefined_frames);
 
+/* Layered min-sum as the reference's HOST-layered path runs it: Coder::decodeOnceTDMP,
+ * MyLdpc.cpp:889-976, over decodeInitTDMP / refreshQTDMP / refreshRTDMP / refreshPostPTDMP /
+ * hardDecisionTDMP / checkResult / checkDones (decodeCL.c:88-108, 203-300).  Same schedule as
+ * above, but the check node of the MS kernel chain (sign = XOR of `< 0`, magnitude = fmin chain
+ * from 1000) and the three-way hard decision after the last layer (P > 0 -> 0, P < 0 -> 1, else
+ * the bit stays; bits start at 0 here -- the reference leaves that buffer uninitialised).  The
+ * reference sizes its layers as hRowRange[l + z] - hRowRange[l] (:907, :958), which is the edge
+ * count of layer l only when all rows have the same weight: returns -3 for any other H. */
+int oracle_decode_layered_host(const oracle_graph *g, int32_t layer_rows, const float *y,
+                               int64_t frames, int max_iter, int pack_mode, uint8_t *out,
+                               int64_t out_bytes, int32_t *iters, uint8_t *hard_out,
+                               const oracle_taps *taps);
+
 /* Fused flooding min-sum with the arithmetic of decodeOnceMS, decodeCL.c:432-567
  * (DecodeMSCL; the reference hard-codes 120 iterations). */
 int oracle_decode_ms_fused(const oracle_graph *g, const float *y, int64_t frames, int max_iter,

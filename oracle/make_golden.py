@@ -59,6 +59,19 @@ MSCL_CASES = [
 ]
 
 
+# host-layered path (DecodeTDMP, MyLdpc.cpp:889-976): only the seeds whose rows all have the same
+# weight -- 2/3A (10) and 5/6 (20) -- where the reference's layer sizes are right
+# (name, rate index, N, sigma, frames, seed, tap_iter)
+TDMP_HOST_CASES = [
+    ("t672_23a", 1, 672, 0.62, 6, 41, 2),
+    ("t2304_23a", 1, 2304, 0.66, 4, 42, 2),
+    ("t2304_23a_hard", 1, 2304, 0.80, 3, 43, 3),
+    ("t576_56", 5, 576, 0.42, 8, 44, 1),
+    ("t1152_56", 5, 1152, 0.47, 4, 45, 2),
+    ("t2304_56_hard", 5, 2304, 0.60, 3, 46, 2),
+]
+
+
 def channel(N, frames, sigma, seed):
     rng = np.random.Generator(np.random.Philox(key=[20260101, seed]))
     return (1.0 + sigma * rng.standard_normal((frames, N))).astype(np.float32)
@@ -102,6 +115,19 @@ def main():
         np.savez_compressed(os.path.join(OUT, "mscl_%s.npz" % name), rate=rate, N=N, K=K, z=z,
                             sigma=sigma, times=120, y=y, out=out)
         print("mscl", name, "z", z)
+    for name, rate, N, sigma, B, seed, tap in TDMP_HOST_CASES:
+        rows, cols = oracle.wimax_edges(rate, N)
+        z = N // 24
+        mb = len(SEEDS[rate])
+        M = mb * z
+        K = N - M
+        rg = rk.RefGraph(rows, cols, M, N, K)
+        y = channel(N, B, sigma, seed)
+        r = rk.decode_tdmp_host(rg, z, y, times=40, tap_iter=tap)
+        np.savez_compressed(os.path.join(OUT, "tdmphost_%s.npz" % name), rate=rate, N=N, K=K, M=M, z=z, sigma=sigma,
+                            times=40, tap_iter=tap, y=y, out=r["out"], hard=r["hard"], time=r["time"], flags=r["flags"],
+                            tap_r=r["taps"]["r"], tap_post=r["taps"]["post"])
+        print("tdmp-host", name, "z", z, "time", r["time"], "clean", int((r["flags"] == 0).sum()), "/", B)
     # graph construction facts the survey measured on the reference's own H builder
     # (E printed by the reference's initCheckMatrix + adjacency build)
     np.savez_compressed(os.path.join(OUT, "graph_facts.npz"),

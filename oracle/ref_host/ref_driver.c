@@ -5,6 +5,8 @@
  *   ref_decode_ms   <- Coder::decodeOnceMS   MyLdpc.cpp:786-848
  *   ref_decode_sp   <- Coder::decodeOnceSP   MyLdpc.cpp:977-1059
  *   ref_decode_tdmp <- Coder::decodeOnceTDMPCL MyLdpc.cpp:850-868 (fused kernel)
+ *   ref_decode_tdmp_host <- Coder::decodeOnceTDMP MyLdpc.cpp:889-976 (host-layered; valid for
+ *                      seeds whose rows all have the same weight, see below)
  * One kernel call = one work-item; an NDRange (B, G) is the double loop below.
  * The graph arrays are the reference's linked-list form (MyLdpc.cpp:171-222),
  * built by the caller (oracle/make_golden.py) from the CSR/CSC form.
@@ -52,6 +54,17 @@ void decodeOnceTDMP(float *postCode, char *srcCode, const char z, const char see
 
 void decodeOnceMS(float *postCode, char *srcCode, const char z, const char seedRowLength, char *hSeed,
                   float *lP, float *lR, bool *srcBool, bool *flag);
+
+void decodeInitTDMP(int *hCols, float *postCodes, float *lQ, const int ldpcN, const int nonZeros,
+                    bool *isDones, float *lPostP, const int blockHeavy, float *lR);
+void refreshRTDMP(int *hRows, float *lQ, float *lR, int *hRowFirstPtr, int *hRowNextPtr,
+                  const int nonZeros, bool *isDones, const int blockHeavy, const int offset);
+void refreshPostPTDMP(float *lR, float *lQ, float *lPostP, int *hCols, const int ldpcN,
+                      const int nonZeros, bool *isDones, const int blockHeavy, const int offset);
+void hardDecisionTDMP(float *lPostP, bool *srcBool, bool *flags, const int ldpcN, bool *isDones);
+void refreshQTDMP(int *hCols, float *lQ, float *lR, float *lPostP, const int ldpcN, const int nonZeros,
+                  bool *flags, bool *isDones, const int blockHeavy, const int offset);
+void checkDones(bool *flags, bool *isDones);
 
 #define NDRANGE2(B, G, CALL)                                   \
     for (int b_ = 0; b_ < (B); ++b_)                           \
@@ -272,4 +285,60 @@ int ref_decode_mscl(int z, int seedRows, char *hSeed, float *postCode, int B, ch
     pthread_attr_destroy(&attr);
     free(th); free(args); free(lP); free(lR); free(srcBool);
     return 0;
+}
+
+
+/* Coder::decodeOnceTDMP, MyLdpc.cpp:889-976 (kernels bound at :440-500: decodeInitTDMP, refreshRTDMP,
+ * refreshQTDMP, refreshPostPTDMP, hardDecisionTDMP, the shared checkResult / checkDones / toChar),
+ * statement for statement -- INCLUDING the layer size `hRowRange[blockRow + z] - hRowRange[blockRow]`
+ * (:907, :958), which indexes hRowRange with the layer number instead of the layer's first row.  It
+ * equals the edges of layer `blockRow` exactly when every window of z rows holds the same number of
+ * edges, i.e. for seeds whose rows all have the same weight (2/3A, 5/6); the caller only uses those.
+ * hRowRange: [M + 1] first edge of each row.  Returns the batch's `time`. */
+int ref_decode_tdmp_host(const ref_graph *g, const int *hRowRange, int z, float *postCode, int B, int times,
+                         char *srcCode, uint8_t *hard_out, uint8_t *flags_out, const ref_taps *taps)
+{
+    const int N = g->N, M = g->M, E = g->E, K = g->K;
+    const int blockHeavy = N;                                                         /* :441 */
+    float *lR = calloc((size_t)B * E, sizeof(float));
+    float *lQ = calloc((size_t)B * blockHeavy, sizeof(float));
+    float *lPostP = calloc((size_t)B * N, sizeof(float));
+    bool *srcBool = calloc((size_t)B * N, 1);     /* zero-initialised (the reference leaves it undefined) */
+    bool *flags = calloc((size_t)B, 1), *isDones = calloc((size_t)B, 1);
+    int time = 0;
+    clh_group_barrier = NULL;
+
+    NDRANGE2(B, N + 1, decodeInitTDMP(g->hCols, postCode, lQ, N, E, isDones, lPostP, blockHeavy, lR));  /* :899-901 */
+    int offset = 0, blockRow = 0;
+    int threadNum = hRowRange[blockRow + z] - hRowRange[blockRow];                     /* :905-907 */
+    while (1) {
+        NDRANGE2(B, threadNum, refreshRTDMP(g->hRows, lQ, lR, g->hRowFirstPtr, g->hRowNextPtr, E, isDones,
+                                            blockHeavy, offset));                      /* :910-913 */
+        NDRANGE2(B, threadNum, refreshPostPTDMP(lR, lQ, lPostP, g->hCols, N, E, isDones, blockHeavy, offset)); /* :915-919 */
+        ++blockRow;
+        offset += threadNum;
+        if (blockRow == M / z) {                                                       /* :923 */
+            NDRANGE2(B, N + 1, hardDecisionTDMP(lPostP, srcBool, flags, N, isDones));  /* :924-927 */
+            NDRANGE2(B, M, checkResult(srcBool, g->hCols, g->hRowFirstPtr, g->hRowNextPtr, M, N, E, flags, isDones)); /* :929 */
+            NDRANGE2(B, 1, checkDones(flags, isDones));                                /* :934 */
+            ++time;
+            if (taps && taps->iter == time) {
+                copy_if(taps->a, lR, (size_t)B * E);
+                copy_if(taps->b, lPostP, (size_t)B * N);
+            }
+            int sumFlag = 0;
+            for (int i = 0; i < B; ++i) if (flags[i]) ++sumFlag;                       /* :945-948 */
+            if (sumFlag == 0) break;
+            if (time == times) break;
+            blockRow = 0;
+            offset = 0;
+        }
+        threadNum = hRowRange[blockRow + z] - hRowRange[blockRow];                     /* :958 */
+        NDRANGE2(B, threadNum, refreshQTDMP(g->hCols, lQ, lR, lPostP, N, E, flags, isDones, blockHeavy, offset)); /* :959-963 */
+    }
+    NDRANGE2(B, K / 8, toChar(srcBool, srcCode, N, K));                                /* :967 */
+    if (hard_out) memcpy(hard_out, srcBool, (size_t)B * N);
+    if (flags_out) memcpy(flags_out, flags, (size_t)B);
+    free(lR); free(lQ); free(lPostP); free(srcBool); free(flags); free(isDones);
+    return time;
 }

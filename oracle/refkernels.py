@@ -45,6 +45,9 @@ def lib():
             f.restype = ctypes.c_int
             f.argtypes = [ctypes.POINTER(_RefGraph), _fp, ctypes.c_int, ctypes.c_int,
                           ctypes.c_char_p, _u8p, _u8p, ctypes.POINTER(_RefTaps)]
+        L.ref_decode_tdmp_host.restype = ctypes.c_int
+        L.ref_decode_tdmp_host.argtypes = [ctypes.POINTER(_RefGraph), _ip, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_char_p, _u8p, _u8p, ctypes.POINTER(_RefTaps)]
         L.ref_decode_mscl.restype = ctypes.c_int
         L.ref_decode_mscl.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, _fp, ctypes.c_int,
                                       ctypes.c_char_p]
@@ -151,3 +154,34 @@ def decode_mscl_fused(z, seed, y):
     if rc:
         raise RuntimeError("ref_decode_mscl rc=%d" % rc)
     return out
+
+
+def decode_tdmp_host(g, z, y, times=40, tap_iter=0):
+    """Run the reference's HOST-layered path (Coder::decodeOnceTDMP, MyLdpc.cpp:889-976, over the
+    *TDMP kernels decodeCL.c:203-300) for one batch.  Only meaningful when every row of H has the
+    same weight (the reference's layer sizes are wrong otherwise); raises if not.
+    Returns dict(out, time, hard, flags, taps={r, post})."""
+    L = lib()
+    y = np.ascontiguousarray(y, np.float32).reshape(-1, g.N)
+    B = y.shape[0]
+    row_range = np.zeros(g.M + 1, np.int32)
+    np.add.at(row_range, g.rows + 1, 1)
+    w = row_range[1:]
+    if not (w == w[0]).all():
+        raise ValueError("rows of different weight: the reference's host-layered path mis-sizes its layers")
+    row_range = np.ascontiguousarray(np.cumsum(row_range), np.int32)
+    out = np.zeros((B - 1) * g.K // 8 + g.K // 8, np.uint8)
+    hard = np.zeros((B, g.N), np.uint8)
+    flags = np.zeros(B, np.uint8)
+    taps = {}
+    ct = None
+    if tap_iter:
+        ct = _RefTaps()
+        ct.iter = tap_iter
+        for field, nm, n in (("a", "r", g.E), ("b", "post", g.N)):
+            taps[nm] = np.full((B, n), np.nan, np.float32)
+            setattr(ct, field, taps[nm].ctypes.data_as(_fp))
+    time = L.ref_decode_tdmp_host(ctypes.byref(g._c), row_range.ctypes.data_as(_ip), z, y.ctypes.data_as(_fp), B, times,
+                                  out.ctypes.data_as(ctypes.c_char_p), hard.ctypes.data_as(_u8p),
+                                  flags.ctypes.data_as(_u8p), ctypes.byref(ct) if ct is not None else None)
+    return dict(out=out, time=time, hard=hard, flags=flags, taps=taps)

@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FLOOD = golden_files("flood")
 LAYERED = golden_files("layered")
 MSCL = golden_files("mscl")
+TDMPHOST = golden_files("tdmphost")
 f32 = np.float32
 
 
@@ -670,3 +671,66 @@ def test_device_side_tail_for_asynchronous_callers(built, algo, f16):
     o2, i2 = dec.decode(y[:300])
     assert np.array_equal(i2, want["iters"][:300]) and np.array_equal(o2, want["out"][:300 * K // 8])
     dec.close()
+
+
+@pytest.mark.parametrize("path", TDMPHOST, ids=lambda p: p.split("tdmphost_")[-1][:-4])
+@pytest.mark.parametrize("V", [1, 2, 4])
+def test_host_layered_bit_exact_vs_reference_host_path(built, path, V):
+    """LDPC_ALGO_LAYERED_HOST (DecodeTDMP where the reference's host-layered path is well defined:
+    seeds 2/3A and 5/6, all rows of one weight) against what the reference's own *TDMP kernels
+    produced under its host loop (MyLdpc.cpp:889-976): bytes, all hard bits, `Time=`, converged
+    count, and the messages and posteriors of one iteration, 0 ulp."""
+    gd = load_golden(path)
+    g, og, K, M, z = _graph(int(gd["rate"]), int(gd["N"]))
+    y, tap = gd["y"], int(gd["tap_iter"])
+    B = y.shape[0]
+    dec = L.Decoder(g, K, max_batch=B, algo="layered_host", max_iter=int(gd["times"]), layer_rows=z, frames_per_lane=V)
+    out, iters = dec.decode(y)
+    assert np.array_equal(out, gd["out"])
+    st = dec.stats()
+    assert st["batch_time"] == int(gd["time"]) and st["frames_converged"] == int((gd["flags"] == 0).sum())
+    o = oracle.decode(og, y, "layered_host", max_iter=int(gd["times"]), layer_rows=z)
+    assert np.array_equal(iters, o["iters"])
+    assert np.array_equal(dec.dump(3, B).astype(np.uint8), gd["hard"])
+    dec.set_tap(tap)
+    dec.decode(y)
+    run = np.nonzero(o["iters"] >= tap)[0]
+    assert np.array_equal(dec.dump(0, B)[run], gd["tap_r"][run], equal_nan=True)
+    assert np.array_equal(dec.dump(2, B)[run], gd["tap_post"][run], equal_nan=True)
+    dec.close()
+
+
+def test_host_layered_degenerate_values_and_the_cpp_class(built, tmp_path):
+    """Zeros, ties, infinities and NaNs through LDPC_ALGO_LAYERED_HOST against the oracle (the
+    three-way hard decision keeps a bit where P is 0 or NaN), a ragged multi-group batch, and
+    Coder::addDecodeType(DecodeTDMP) choosing this path for rate 5/6 and 2/3A."""
+    g, og, K, M, z = _graph(codes.RATE_5_6, 960)
+    rng = np.random.default_rng(23)
+    y = channel.awgn_frames(960, 0, 150, 0.45, seed=23)
+    y[0, rng.choice(960, 200, replace=False)] = 0.0
+    y[1, :] = 0.0
+    y[2, rng.choice(960, 30, replace=False)] = np.inf
+    y[3, rng.choice(960, 30, replace=False)] = -np.inf
+    y[4, rng.choice(960, 5, replace=False)] = np.nan
+    y[5, :] = 1.0
+    y[6, :] = -1.0
+    y[7, rng.choice(960, 300, replace=False)] *= 400.0
+    want = oracle.decode(og, y, "layered_host", max_iter=15, layer_rows=z)
+    dec = L.Decoder(g, K, max_batch=64, algo="layered_host", max_iter=15, layer_rows=z)
+    out, iters = dec.decode(y)
+    assert np.array_equal(out, want["out"]) and np.array_equal(iters, want["iters"])
+    dec.close()
+    exe = str(tmp_path / "coder_roundtrip")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "coder_roundtrip.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "myldpccppapi_amd"), "-lmyldpc", "-lldpc_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "myldpccppapi_amd")])
+    for rate, N, K2 in ((5, 960, 800), (1, 672, 448)):
+        pre = str(tmp_path / ("tdmp%d" % rate))
+        r = subprocess.run([exe, str(rate), str(N), "3000", "16", "5.5", "TDMP", "7", "--dump", pre], capture_output=True, text=True)
+        assert r.returncode == 0 and "ErrNum=0" in r.stdout, r.stdout + r.stderr
+        g2, og2, Kc, Mc, zc = _graph(rate, N)
+        assert Kc == K2
+        post = np.fromfile(pre + ".post", np.float32).reshape(-1, N)
+        ref = oracle.decode(og2, post, "layered_host", max_iter=40, layer_rows=zc)["out"]
+        assert np.array_equal(np.fromfile(pre + ".out", np.uint8), ref[:3000])

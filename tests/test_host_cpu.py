@@ -80,6 +80,17 @@ def test_bad_config_is_rejected_before_touching_the_device(built):
         assert e.value.code == 1, kw
 
 
+def test_host_layered_algo_is_refused_where_the_reference_is_wrong(built):
+    """LDPC_ALGO_LAYERED_HOST exists only for H whose rows all have one weight: elsewhere the
+    reference's host-layered path mis-sizes its layers (MyLdpc.cpp:907,958).  Refused with
+    LDPC_ERR_UNSUPPORTED before the device is touched."""
+    rows, cols = codes.wimax_edges(codes.RATE_1_2, 576)
+    g = L.Graph(rows, cols, 288, 576)
+    with pytest.raises(L.LdpcError) as e:
+        L.Decoder(g, 288, 4, algo="layered_host", layer_rows=24)
+    assert e.value.code == 4 and "same weight" in str(e.value)
+
+
 def test_tuning_fields_are_validated_and_no_environment_is_read(built):
     """The tuning knobs live in the config (two-bit fields + integers); out-of-range values are
     argument errors before the device is touched, and the library never calls getenv."""

@@ -9,6 +9,7 @@ from util import assert_taps_equal, golden_files, load_golden, wimax_oracle_grap
 FLOOD = golden_files("flood")
 LAYERED = golden_files("layered")
 MSCL = golden_files("mscl")
+TDMPHOST = golden_files("tdmphost")
 
 
 def test_fixtures_present():
@@ -59,6 +60,31 @@ def test_fused_flooding_matches_reference_kernel(path):
     o = oracle.decode(g, gd["y"], "ms_fused", max_iter=int(gd["times"]))
     assert not o["undefined"].any()
     assert np.array_equal(o["out"], gd["out"])
+
+
+@pytest.mark.parametrize("path", TDMPHOST, ids=lambda p: p.split("tdmphost_")[-1][:-4])
+def test_host_layered_matches_reference_host_path(path):
+    """DecodeTDMP as the reference's HOST drives it (MyLdpc.cpp:889-976 over the *TDMP kernels,
+    decodeCL.c:203-300), on the seeds whose rows all have one weight (2/3A, 5/6) -- the only ones
+    for which the reference's layer sizes are right: bytes, all hard bits, `Time=`, flags and one
+    iteration's messages and posteriors, bit for bit."""
+    gd = load_golden(path)
+    g, rows, cols, K, M, z = wimax_oracle_graph(int(gd["rate"]), int(gd["N"]))
+    tap = int(gd["tap_iter"])
+    o = oracle.decode(g, gd["y"], "layered_host", max_iter=int(gd["times"]), layer_rows=z, tap_iter=tap)
+    assert np.array_equal(o["out"], gd["out"])
+    assert np.array_equal(o["hard"], gd["hard"])
+    assert int(o["iters"].max()) == int(gd["time"])
+    converged = gd["flags"] == 0
+    assert (o["iters"][~converged] == int(gd["times"])).all()
+    assert_taps_equal(o["taps"]["r"], gd["tap_r"], o["iters"] >= tap, "lR")
+    assert_taps_equal(o["taps"]["post"], gd["tap_post"], o["iters"] >= tap, "lPostP")
+
+
+def test_host_layered_is_refused_where_the_reference_is_wrong():
+    g, *_ = wimax_oracle_graph(0, 576)          # rate 1/2: row weights 6 and 7
+    with pytest.raises(ValueError):
+        oracle.decode(g, np.ones((1, 576), np.float32), "layered_host", layer_rows=24)
 
 
 def test_ms_equals_cpu_decoder_packing_when_k_is_byte_aligned():

@@ -34,6 +34,10 @@ def display(name):
     if m:
         algo = ("sp", "ms")[int(m.group(2))] + ("16" if m.group(5) != "float" else "")
         return "%s<%s,%s,%s>" % (m.group(1), algo, m.group(3), m.group(4))
+    m = re.match(r"(check_group_kernel|var_group_kernel)<(\d), (\d), (float|_Float16), (\d+), (\d+)>", name)
+    if m:
+        algo = ("sp", "ms")[int(m.group(2))] + ("16" if m.group(4) != "float" else "")
+        return "%s<%s,%s-%s,%s>" % (m.group(1), algo, m.group(5), m.group(6), m.group(3))
     m = re.match(r"layer_kernel<(\d+), (\d)>", name)
     if m:
         return "layer_kernel<layered,%s,%s>" % (m.group(1), m.group(2))
@@ -53,7 +57,7 @@ if stats:
                      r["Percentage"], r["MinNs"], r["MaxNs"]])
     with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 (MI355X, 1 GPU)"])
+        w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras (MI355X, 1 GPU)"])
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         w.writerows(rows)
 
@@ -81,13 +85,21 @@ for k, v in pmc.items():
         # wave-instruction): every Q byte is read exactly once (no reuse is possible), the
         # algorithmic read volume is 3.716 GB per launch and the raw counter shows 1.859 GB,
         # i.e. exactly 1/2 as well.
-        wide = bool(re.search(r"^(var_kernel|layer_kernel|check_kernel|check_link_kernel|check_link_narrow_kernel)<", k))
+        wide = bool(re.search(r"^(var_kernel|var_group_kernel|layer_kernel|check_kernel|check_group_kernel|check_link_kernel|check_link_narrow_kernel)<", k))
         fetch = v["FETCH_SIZE_KiB_per_launch"] * 1024 * (2 if wide else 1)
         write = v["WRITE_SIZE_KiB_per_launch"] * 1024
         v["fetch_correction"] = 2 if wide else 1
         v["hbm_bytes_per_launch"] = fetch + write
         traffic[display(k)] = int(fetch + write)
 if pmc:
+    # which launch shape the byte counts belong to (bench.py scales them per frame and says so)
+    cfg = {"source": "profiles/%s_pmc_traffic.json" % tag}
+    try:
+        line = [l for l in open(os.path.join(src, "bench_pmc_fetch.json")) if l.startswith("{")][-1]
+        cfg["frames_per_gpu"] = json.loads(line)["config"]["frames_per_gpu"]
+    except Exception:
+        cfg["frames_per_gpu"] = 4096
+    traffic["__config__"] = cfg
     json.dump(pmc, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1, sort_keys=True)
 for k in sorted(pmc):
