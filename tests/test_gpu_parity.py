@@ -725,9 +725,9 @@ def test_host_layered_degenerate_values_and_the_cpp_class(built, tmp_path):
                            os.path.join(ROOT, "tests", "cpp", "coder_roundtrip.cpp"), "-o", exe,
                            "-L" + os.path.join(ROOT, "myldpccppapi_amd"), "-lmyldpc", "-lldpc_hip",
                            "-Wl,-rpath," + os.path.join(ROOT, "myldpccppapi_amd")])
-    for rate, N, K2 in ((5, 960, 800), (1, 672, 448)):
+    for rate, N, K2, snr in ((5, 960, 800, "8"), (1, 672, 448, "5.5")):
         pre = str(tmp_path / ("tdmp%d" % rate))
-        r = subprocess.run([exe, str(rate), str(N), "3000", "16", "5.5", "TDMP", "7", "--dump", pre], capture_output=True, text=True)
+        r = subprocess.run([exe, str(rate), str(N), "3000", "16", snr, "TDMP", "7", "--dump", pre], capture_output=True, text=True)
         assert r.returncode == 0 and "ErrNum=0" in r.stdout, r.stdout + r.stderr
         g2, og2, Kc, Mc, zc = _graph(rate, N)
         assert Kc == K2
