@@ -128,7 +128,8 @@ enum ldpc_tune_field {
     LDPC_TUNE_FUSED_LOOP = 16,  /* fused kernels: run-time row loops instead of unrolled (default off) */
     LDPC_TUNE_DEVICE_TAIL = 18, /* device-side early exit + tail compaction without host polling
                                    (default: on when early_term && poll_interval == 0)              */
-    LDPC_TUNE_MERGE = 20        /* degree classes of one bucket share a launch (default on)         */
+    LDPC_TUNE_MERGE = 20,       /* degree classes of one bucket share a launch (default on)         */
+    LDPC_TUNE_LINK_DEEP = 22    /* column-fused check kernel requests its inputs two rows ahead     */
 };
 #define LDPC_TUNE_ON(field) (1 << (field))
 #define LDPC_TUNE_OFF(field) (2 << (field))

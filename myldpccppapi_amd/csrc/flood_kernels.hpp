@@ -841,6 +841,126 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow_kernel(const CheckAr
     }
 }
 
+/* The same kernel with the row inputs requested TWO rows ahead (three buffers in rotation): a wave
+ * of the kernel above has one row (7 x 256 B) in flight while it works -- 57 KB per CU at 32 waves --
+ * and runs at 83-94 % of the box's copy rate depending on the box; this one keeps two. */
+template <int ALGO, int D, int V, typename T>
+__global__ __launch_bounds__(kBlock) void check_link_narrow2_kernel(const CheckArgs a, const LinkArgs g)
+{
+    constexpr size_t F = 64 * V;
+    constexpr int FB = 64 / V;                       /* bits per field */
+    const int lane = threadIdx.x & 63;
+    const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
+    if (tile < 0) return;
+    if ((int)blockIdx.x >= g.link_blocks) { link_extra_rows<ALGO, V, T>(a, g, tile); return; }
+    const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
+    const int sub = wave % V;
+    const int r_begin = (wave / V) * a.rows_per_wave;
+    const int r_end = min(r_begin + a.rows_per_wave, a.n_rows);
+    const size_t lane_off = (size_t)sub * 64 + lane;
+    const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + lane_off;
+    T *Qwt = static_cast<T *>(g.Qw) + (size_t)tile * (size_t)a.E * F + lane_off;
+    T *Rt = static_cast<T *>(a.R) + (size_t)tile * (size_t)a.E * F + lane_off;
+    const T *chan_t = static_cast<const T *>(g.chan) + (size_t)tile * (size_t)g.N * F + lane_off;
+    /* this lane's frame 64*sub + lane = V*l' + v'  ->  word v' = lane % V, bit sub*FB + lane / V */
+    const int my_word = lane % V, my_bit = lane / V;
+    uint8_t *hard_b = reinterpret_cast<uint8_t *>(g.hard + (size_t)tile * (size_t)g.N * V) + (size_t)sub * (FB / 8);
+    /* frozen frames of this sub-wave, per word (lanes 0..V-1 keep the field of word `lane`) */
+    const uint64_t frozen_field = (a.done[(size_t)tile * V + (lane < V ? lane : 0)] >> (sub * FB)) &
+                                  (FB == 64 ? ~0ull : ((1ull << FB) - 1ull));
+
+    auto load_field = [&](int col, int word) -> uint64_t {
+        const uint8_t *p = hard_b + ((size_t)col * V + word) * 8;
+        if (V == 1) return *reinterpret_cast<const uint64_t *>(p);
+        if (V == 2) return *reinterpret_cast<const uint32_t *>(p);
+        return *reinterpret_cast<const uint16_t *>(p);
+    };
+
+    int pend_col = -1, pend_edge = 0, pend_kb = 0;
+    float pend_r = 0.0f;
+    /* three row buffers in rotation: while row r is worked on, rows r+1 and r+2 are in flight */
+    float b0[D], b1[D], b2[D];
+    auto load_row = [&](float (&dst)[D], int r) {
+        const int e = a.cls_e0[r];
+#pragma unroll
+        for (int k = 0; k < D; ++k) { float t[1]; vload<1>(t, Qt + (size_t)(e + k) * F); dst[k] = t[0]; }
+    };
+    if (r_begin < r_end) load_row(b0, r_begin);
+    if (r_begin + 1 < r_end) load_row(b1, r_begin + 1);
+    auto step = [&](int r, float (&x)[D], float (&pre)[D]) {
+        const int e0 = a.cls_e0[r];
+        const int next_col = (r + 1 < r_end) ? g.link_col[r] : -1;
+        const int pos = g.link_pos[r];
+        const int ka = next_col >= 0 ? (pos & 255) : -1;
+        const int kb = pend_col >= 0 ? pend_kb : -1;
+        float ch[1] = {0.0f};
+        uint64_t old_mine = 0;
+        if (pend_col >= 0) {
+            vload<1>(ch, chan_t + (size_t)pend_col * F);
+            old_mine = load_field(pend_col, my_word);
+        }
+        if (r + 2 < r_end) load_row(pre, r + 2);
+        float xx[D][1], out[D][1];
+#pragma unroll
+        for (int k = 0; k < D; ++k) xx[k][0] = x[k];
+        if (ALGO == kAlgoSP) check_sp<D, 1>(xx, out); else check_ms<D, 1>(xx, out);
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            if ((k != ka && k != kb) || g.store_all) vstore<1>(Rt + (size_t)(e0 + k) * F, out[k]);
+
+        if (pend_col >= 0) {
+            float rr[2][1], q[2][1];
+            rr[0][0] = pend_r;
+            float t = out[0][0];
+#pragma unroll
+            for (int k = 1; k < D; ++k) t = (k == kb) ? out[k][0] : t;
+            rr[1][0] = t;
+            bool bit;
+            if (ALGO == kAlgoSP) {
+                float f0[1], f1[1];
+                var_sp<2, 1>(ch, rr, q, f0, f1);
+                const bool oldb = (old_mine >> my_bit) & 1ull;
+                bit = (f0[0] > f1[0]) ? false : ((f0[0] < f1[0]) ? true : oldb);
+            } else {
+                float p = ch[0];
+                p += rr[0][0];
+                p += rr[1][0];
+                q[0][0] = p - rr[0][0];
+                q[1][0] = p - rr[1][0];
+                bit = !(p > 0.0f);
+            }
+            const uint64_t ballot = __ballot(bit);
+            if (lane < V) {
+                const uint64_t nf = compress_stride<V>(ballot >> lane);
+                const uint64_t of = load_field(pend_col, lane);
+                const uint64_t res = (of & frozen_field) | (nf & ~frozen_field);
+                uint8_t *p = hard_b + ((size_t)pend_col * V + lane) * 8;
+                if (V == 1) *reinterpret_cast<uint64_t *>(p) = res;
+                else if (V == 2) *reinterpret_cast<uint32_t *>(p) = (uint32_t)res;
+                else *reinterpret_cast<uint16_t *>(p) = (uint16_t)res;
+            }
+            if (g.write_q) {
+                vstore<1>(Qwt + (size_t)pend_edge * F, q[0]);
+                vstore<1>(Qwt + (size_t)(e0 + kb) * F, q[1]);
+            }
+        }
+        pend_col = next_col;
+        if (next_col >= 0) {
+            pend_edge = e0 + ka;
+            pend_kb = (pos >> 8) & 255;
+            float t = out[0][0];
+#pragma unroll
+            for (int k = 1; k < D; ++k) t = (k == ka) ? out[k][0] : t;
+            pend_r = t;
+        }
+    };
+    for (int r = r_begin; r < r_end; r += 3) {
+        step(r, b0, b2);
+        if (r + 1 < r_end) step(r + 1, b1, b0);
+        if (r + 2 < r_end) step(r + 2, b2, b1);
+    }
+}
+
 /* The variable node keeps WIDE waves (V values per lane, whole 64*V-frame segments per
  * wave-instruction): narrow waves as in check_kernel were measured 10 % slower here
  * (1.69 vs 1.53 ms per round at B = 4096), 2 values per lane no faster (1.11 vs 1.12 ms) --

@@ -147,15 +147,16 @@ template <int V, typename T> struct CheckTableMS<V, T, ldpc::kMaxUnrolledDegree>
 
 using LinkFn = void (*)(const ldpc::CheckArgs, const ldpc::LinkArgs);
 template <int ALGO, int V, typename T, int D> struct LinkTable {
-    static void fill(LinkFn *t, LinkFn *tn)
+    static void fill(LinkFn *t, LinkFn *tn, LinkFn *td)
     {
         t[D] = ldpc::check_link_kernel<ALGO, D, V, T>;
         tn[D] = ldpc::check_link_narrow_kernel<ALGO, D, V, T>;
-        LinkTable<ALGO, V, T, D - 1>::fill(t, tn);
+        td[D] = ldpc::check_link_narrow2_kernel<ALGO, D, V, T>;
+        LinkTable<ALGO, V, T, D - 1>::fill(t, tn, td);
     }
 };
 template <int ALGO, int V, typename T> struct LinkTable<ALGO, V, T, 1> {
-    static void fill(LinkFn *, LinkFn *) {}
+    static void fill(LinkFn *, LinkFn *, LinkFn *) {}
 };
 
 /* group launches (several degree classes of a bucket in one launch, flood_kernels.hpp) */
@@ -254,6 +255,8 @@ struct ldpc_decoder {
     int max_check_unrolled = ldpc::kMaxUnrolledDegree;
     LinkFn link_fn[ldpc::kMaxUnrolledDegree + 1] = {};        /* wide waves */
     LinkFn link_narrow_fn[ldpc::kMaxUnrolledDegree + 1] = {}; /* narrow waves */
+    LinkFn link_deep_fn[ldpc::kMaxUnrolledDegree + 1] = {};   /* narrow waves, inputs two rows ahead */
+    int tune_link_deep = 0;
     ldpc::Tune tune;                    /* cfg.tune_* unpacked (tune.hpp) */
     int tune_link_narrow = 1;           /* 0: wide linked check kernel */
     int link_rpw = 16;                  /* rows per wave of the fused check kernel; 0 = fusion off */
@@ -490,7 +493,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             const int waves = ((rc.count + d->link_rpw - 1) / d->link_rpw) * (nar ? V : 1);
             lk.link_blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
             dim3 grid(lk.link_blocks + (d->n_extra + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
-            (nar ? d->link_narrow_fn : d->link_fn)[rc.degree]<<<grid, kBlock, 0, s>>>(a, lk);
+            (nar ? (d->tune_link_deep ? d->link_deep_fn : d->link_narrow_fn) : d->link_fn)[rc.degree]<<<grid, kBlock, 0, s>>>(a, lk);
             HIP_TRY(span_end(d, s));
         }
         for (auto &g : d->check_groups) {
@@ -758,7 +761,7 @@ int setup_flooding(ldpc_decoder *d, const ldpc_graph *g, size_t TF)
 #define LDPC_FILL(ALGO, TYPE, VV)                                                      \
     do {                                                                               \
         FloodTable<ALGO, VV, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn); \
-        LinkTable<ALGO, VV, TYPE, DM>::fill(d->link_fn, d->link_narrow_fn);            \
+        LinkTable<ALGO, VV, TYPE, DM>::fill(d->link_fn, d->link_narrow_fn, d->link_deep_fn); \
         GroupTable<ALGO, VV, TYPE>::fill(d->check_group_fn, d->var_group_fn);          \
         d->init_fn = pick_init<ALGO, TYPE>(VV);                                        \
         if (ALGO == kAlgoMS) {   /* min-sum rows of degree 17..32: narrow unrolled kernels */ \
@@ -937,6 +940,7 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     d->tune_syn_xcd = ldpc::tune_pick(tune.syn_xcd, true);
     d->tune_check_wide = ldpc::tune_pick(tune.check_wide, false);
     d->tune_link_narrow = ldpc::tune_pick(tune.link_narrow, true);
+    d->tune_link_deep = ldpc::tune_pick(tune.link_deep, false);
     if (tune.link_rows) d->link_rpw = tune.link_rows < 0 ? 0 : tune.link_rows;
     d->V = pick_frames_per_lane(*cfg, g->max_row_deg, g->max_col_deg);
     d->F = 64 * d->V;

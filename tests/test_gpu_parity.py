@@ -354,9 +354,11 @@ def test_column_local_fusion_on_staircase_code(built, algo):
     og = oracle.Graph(rows, cols, N2 - K2, N2, K2)
     y = channel.awgn_frames(N2, 0, 70, 0.72 if algo == "ms" else 0.8, seed=14)
     want = oracle.decode(og, y, algo, max_iter=25, tap_iter=2)
-    for rpw in (8, 3, -1):
+    for rpw, deep in ((8, False), (3, False), (-1, False), (16, True), (7, True), (2, True)):
         for V in (1, 4):
-            dec = L.Decoder(g, K2, max_batch=70, algo=algo, max_iter=25, frames_per_lane=V, tune={"link_rows": rpw})
+            # deep: the fused check kernel with its inputs requested two rows ahead (check_link_narrow2_kernel)
+            dec = L.Decoder(g, K2, max_batch=70, algo=algo, max_iter=25, frames_per_lane=V,
+                            tune={"link_rows": rpw, "link_deep": deep})
             out, iters = dec.decode(y)
             assert np.array_equal(out, want["out"]) and np.array_equal(iters, want["iters"]), (rpw, V)
             dec.set_tap(2)
