@@ -211,8 +211,9 @@ struct ColClass {
 struct ClassGroup {
     int bucket = 0, lo = 0, hi = 0;
     int blocks = 0;                       /* gridDim.x */
+    int blocks_fat = 0;                   /* ... with kIdleFat times the rows / columns per wave */
     std::vector<int> members;             /* indices into row_classes / col_classes */
-    DevBuf<ldpc::GroupClass> table;
+    DevBuf<ldpc::GroupClass> table, table_fat;
 };
 
 struct TimedSpan {
@@ -296,6 +297,16 @@ struct ldpc_decoder {
     bool tail_enabled = false;
     int TO = 0, TA = 0;
     DevBuf<int32_t> tail_state, tail_map, running;
+    /* Rounds beyond the previous call's iteration count are probably idle: they are launched with
+     * kIdleFat times as many rows / columns per wave, i.e. that many times fewer workgroups (an idle
+     * workgroup costs about a clock of dispatch chip-wide: 312 000 of them per round for the rate-9/10
+     * code at 4096 frames).  The count arrives through a pinned word copied at the end of every call;
+     * it is read only once that copy has completed.  (Block-strided loops inside the kernels were
+     * tried instead and cost 17-27 % at full work: profiles/r02_ab_block_strided_negative.txt.) */
+    int32_t *h_summary = nullptr;       /* pinned [2] */
+    hipEvent_t ev_summary = nullptr;
+    bool summary_pending = false;
+    int idle_after = 0;                 /* 0: no hint */
 
     bool timing = false;                /* the call being enqueued is timed */
     int timing_every = 0;               /* 0 off, k: every k-th device call is timed */
@@ -324,6 +335,8 @@ struct ldpc_decoder {
         if (ev_begin) (void)hipEventDestroy(ev_begin);
         if (ev_end) (void)hipEventDestroy(ev_end);
         if (h_active) (void)hipHostFree(h_active);
+        if (h_summary) (void)hipHostFree(h_summary);
+        if (ev_summary) (void)hipEventDestroy(ev_summary);
         for (auto &sl : slot) {
             if (sl.h_out) (void)hipHostFree(sl.h_out);
             if (sl.h_iters) (void)hipHostFree(sl.h_iters);
@@ -448,6 +461,17 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
     const bool resume = start_round > 1;    /* a child taking over running frames: their state is in place */
     HIP_TRY(hipMemsetAsync(d->failw.p, 0, d->failw.n * sizeof(uint64_t), s));
     HIP_TRY(hipMemsetAsync(d->summary.p, 0, 2 * sizeof(int32_t), s));
+    /* idle hint from the previous call (asynchronous early termination only) */
+    if (!resume && d->summary_pending) {
+        if (hipEventQuery(d->ev_summary) == hipSuccess) {
+            d->summary_pending = false;
+            d->idle_after = (d->h_summary[0] > 0 && d->h_summary[0] < max_iter) ? d->h_summary[0] + 1 : 0;
+        } else {
+            (void)hipGetLastError();        /* "not ready" is not an error of this call */
+        }
+    }
+    const int idle_after = (freeze && !resume && !d->tap_iter && d->cfg.poll_interval == 0) ? d->idle_after : 0;
+    constexpr int kIdleFat = 8;
     /* device-side tail: only when the call has clearly more tiles than the overflow area */
     const bool use_tail = d->tail_enabled && freeze && !resume && !d->tap_iter && tiles >= 4 * d->TO;
     const TailRef tr{use_tail ? d->tail_state.p : nullptr, d->T, d->TO};
@@ -473,6 +497,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
 
     int launched = start_round - 1;
     for (int it = start_round; it <= rounds; ++it) {
+        const bool fat = idle_after > 0 && it > idle_after;      /* probably idle: fewer, fatter workgroups */
         /* check_i: R_i = check(Q_{i-1}) */
         for (auto &rc : d->row_classes) {
             if (!rc.linked) continue;
@@ -500,8 +525,9 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             int64_t edges = 0;
             for (int i : g.members) edges += (int64_t)d->row_classes[i].degree * d->row_classes[i].count;
             HIP_TRY(span_begin(d, s, 5, g.hi, 2 * msz * edges * frames, -1, g.lo));
-            CheckArgs a{d->Q.p, d->R.p, nullptr, d->done.p, d->E, 0, d->tune_rpw ? d->tune_rpw : 2, 0, tr};
-            d->check_group_fn[g.bucket]<<<dim3(g.blocks, tiles), kBlock, 0, s>>>(a, g.table.p, (int)g.members.size());
+            CheckArgs a{d->Q.p, d->R.p, nullptr, d->done.p, d->E, 0, (d->tune_rpw ? d->tune_rpw : 2) * (fat ? kIdleFat : 1), 0, tr};
+            d->check_group_fn[g.bucket]<<<dim3(fat ? g.blocks_fat : g.blocks, tiles), kBlock, 0, s>>>(
+                a, fat ? g.table_fat.p : g.table.p, (int)g.members.size());
             HIP_TRY(span_end(d, s));
         }
         for (int ci : d->check_solo) {
@@ -510,7 +536,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree, tr};
             const int slotk = rc.degree <= d->max_check_unrolled ? rc.degree : 0;
             const bool narrow = slotk && (!d->tune_check_wide || rc.degree > kMaxUnrolledDegree);
-            const int rpw = d->tune_rpw ? d->tune_rpw : (narrow ? 2 : 1);
+            const int rpw = (d->tune_rpw ? d->tune_rpw : (narrow ? 2 : 1)) * (fat ? kIdleFat : 1);
             a.rows_per_wave = rpw;
             const int waves = ((rc.count + rpw - 1) / rpw) * (narrow ? V : 1);
             dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
@@ -524,8 +550,9 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             for (int i : g.members) units += (int64_t)((wq ? 2 : 1) * d->col_classes[i].degree + 1) * d->col_classes[i].count;
             HIP_TRY(span_begin(d, s, 6, g.hi, msz * units * frames, -1, g.lo));
             VarArgs a{d->R.p, d->Q.p, d->chan.p, d->hard.p, d->done.p, nullptr, nullptr,
-                      d->E, d->N, 0, d->tune_cpw ? d->tune_cpw : 1, wq, 0, tr};
-            d->var_group_fn[g.bucket]<<<dim3(g.blocks, tiles), kBlock, 0, s>>>(a, g.table.p, (int)g.members.size());
+                      d->E, d->N, 0, (d->tune_cpw ? d->tune_cpw : 1) * (fat ? kIdleFat : 1), wq, 0, tr};
+            d->var_group_fn[g.bucket]<<<dim3(fat ? g.blocks_fat : g.blocks, tiles), kBlock, 0, s>>>(
+                a, fat ? g.table_fat.p : g.table.p, (int)g.members.size());
             HIP_TRY(span_end(d, s));
         }
         for (int ci : d->var_solo) {
@@ -533,7 +560,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             HIP_TRY(span_begin(d, s, 1, cc.degree, msz * ((wq ? 2 : 1) * cc.degree + 1) * cc.count * frames));
             VarArgs a{d->R.p, d->Q.p, d->chan.p, d->hard.p, d->done.p, cc.col.p, cc.edge.p,
                       d->E, d->N, cc.count, 1, wq, cc.degree, tr};
-            const int cpw = d->tune_cpw ? d->tune_cpw : 1;
+            const int cpw = (d->tune_cpw ? d->tune_cpw : 1) * (fat ? kIdleFat : 1);
             a.cols_per_wave = cpw;
             const int slotk = cc.degree <= kMaxUnrolledDegree ? cc.degree : 0;
             const int waves = (cc.count + cpw - 1) / cpw;
@@ -601,6 +628,12 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
         /* after the final state_kernel `done` marks exactly the converged frames */
         summary_kernel<V><<<(unsigned)((frames + 255) / 256), 256, 0, s>>>(
             d->iters.p, d->done.p, d->failw.p, frames, 1, d->summary.p);
+        if (!d->is_child && d->cfg.poll_interval == 0 && freeze && !d->summary_pending) {
+            /* the next call's idle hint */
+            HIP_TRY(hipMemcpyAsync(d->h_summary, d->summary.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipEventRecord(d->ev_summary, s));
+            d->summary_pending = true;
+        }
     }
     HIP_TRY(span_end(d, s));
     HIP_TRY(hipGetLastError());
@@ -721,22 +754,30 @@ int plan_launches(ldpc_decoder *d)
         groups.emplace_back();
         ClassGroup &g = groups.back();
         g.bucket = bucket; g.lo = lo; g.hi = hi; g.members = members;
-        std::vector<GroupClass> tab;
+        std::vector<GroupClass> tab, tabf;
+        constexpr int fatk = 8;                       /* = kIdleFat of run_flooding */
         for (int i : members) {
             GroupClass gc{};
-            gc.block_begin = g.blocks;
             if (rows) {
                 const RowClass &rc = d->row_classes[i];
                 gc.degree = rc.degree; gc.count = rc.count; gc.ids = rc.e0.p; gc.edges = nullptr;
-                g.blocks += (((rc.count + rpw - 1) / rpw) * V + ldpc::kWavesPerBlock - 1) / ldpc::kWavesPerBlock;
             } else {
                 const ColClass &cc = d->col_classes[i];
                 gc.degree = cc.degree; gc.count = cc.count; gc.ids = cc.col.p; gc.edges = cc.edge.p;
-                g.blocks += ((cc.count + cpw - 1) / cpw + ldpc::kWavesPerBlock - 1) / ldpc::kWavesPerBlock;
             }
+            auto blocks_of = [&](int per_wave) {
+                const int waves = ((gc.count + per_wave - 1) / per_wave) * (rows ? V : 1);
+                return (waves + ldpc::kWavesPerBlock - 1) / ldpc::kWavesPerBlock;
+            };
+            gc.block_begin = g.blocks;
             tab.push_back(gc);
+            g.blocks += blocks_of(rows ? rpw : cpw);
+            gc.block_begin = g.blocks_fat;
+            tabf.push_back(gc);
+            g.blocks_fat += blocks_of((rows ? rpw : cpw) * fatk);
         }
-        return g.table.upload(tab);
+        const hipError_t e = g.table.upload(tab);
+        return e != hipSuccess ? e : g.table_fat.upload(tabf);
     };
     for (int k = 0; k < kCheckBuckets; ++k) HIP_TRY(make(d->check_groups, d->check_solo, cb[k], k, kCheckBucketLo[k], kCheckBucketHi[k], true));
     for (int k = 0; k < kVarBuckets; ++k) HIP_TRY(make(d->var_groups, d->var_solo, vb[k], k, kVarBucketLo[k], kVarBucketHi[k], false));
@@ -953,6 +994,8 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     HIP_TRY(hipEventCreate(&d->ev_begin));
     HIP_TRY(hipEventCreate(&d->ev_end));
     HIP_TRY(hipHostMalloc((void **)&d->h_active, sizeof(int32_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&d->h_summary, 2 * sizeof(int32_t), hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&d->ev_summary, hipEventDisableTiming));
     HIP_TRY(d->row_ptr.upload(g->row_ptr));
     HIP_TRY(d->edge_col.upload(g->cols));
     HIP_TRY(d->col_ptr.upload(g->col_ptr));

@@ -668,6 +668,23 @@ def test_device_side_tail_for_asynchronous_callers(built, algo, f16):
                 assert st["frames_converged"] == n_conv and st["batch_time"] == 30, (tune, fpl)
                 assert st["iterations_launched"] == 30              # asynchronous: every round is enqueued
             dec.close()
+    # Idle hint: an asynchronous decoder remembers the previous call's iteration count and launches later
+    # rounds with fewer, fatter workgroups.  Results must not depend on it -- neither when the hint is
+    # right (the same easy batch again) nor when it is wrong (a batch with stragglers right after).
+    y_easy = channel.awgn_frames(1152, 9000, B, 0.6, seed=46)
+    want_easy = oracle.decode(og, y_easy, algo, max_iter=30, msg_f16=f16)
+    assert want_easy["iters"].max() < 20
+    for fpl in (1, 4):
+        dec = L.Decoder(g, K, max_batch=B, algo=algo, max_iter=30, poll_interval=0, frames_per_lane=fpl,
+                        msg_dtype="f16" if f16 else "f32")
+        for yy, ww in ((y_easy, want_easy), (y_easy, want_easy), (y, want), (y_easy, want_easy)):
+            ydv = torch.from_numpy(yy).cuda()
+            out = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+            it = torch.zeros(B, dtype=torch.int32, device="cuda")
+            dec.decode_device(ydv.data_ptr(), B, out.data_ptr(), nb, it.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), ww["out"]) and np.array_equal(it.cpu().numpy(), ww["iters"]), fpl
+        dec.close()
     # a batch too small for the overflow area simply runs without it
     dec = L.Decoder(g, K, max_batch=300, algo=algo, max_iter=30, msg_dtype="f16" if f16 else "f32")
     o2, i2 = dec.decode(y[:300])
