@@ -1325,24 +1325,33 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
         hipError_t e = hipSuccess;
         const bool last = kk + 1 == ngroups;
         const uintptr_t b1 = last ? (s1 & ~(uintptr_t)4095) : ((s1 + 4095) & ~(uintptr_t)4095);   /* end of the block */
-        if (kk >= 1 && b0 < b1) {
-            if (hipHostRegister((void *)b0, (size_t)(b1 - b0), hipHostRegisterPortable) == hipSuccess) pinned.push_back((void *)b0);
-            else (void)hipGetLastError();
-            const uintptr_t body_end = last ? b1 : s1;               /* the copy stops at the group's data */
-            const size_t head = (size_t)(b0 - s0), body = (size_t)(body_end - b0), tail = (size_t)(s1 - body_end);
-            uint8_t *dst = reinterpret_cast<uint8_t *>(sl.llr.p);
+        uint8_t *dst = reinterpret_cast<uint8_t *>(sl.llr.p);
+        if (kk == 0) {
+            e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->copy_stream);
+        } else {
+            /* the bytes before the first page boundary may share their page with the previous group's
+             * registered block: always through the scratch page, never as a pageable source */
+            const uintptr_t head_end = std::min(s1, b0);
+            const size_t head = (size_t)(head_end - s0);
             if (head) {
                 memcpy(sl.h_head, src, head);
                 e = hipMemcpyAsync(dst, sl.h_head, head, hipMemcpyHostToDevice, d->copy_stream);
             }
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(dst + head, (const void *)b0, body, hipMemcpyHostToDevice, d->copy_stream);
-            if (e == hipSuccess && tail) {
-                memcpy(sl.h_head + 4096, (const void *)body_end, tail);
-                e = hipMemcpyAsync(dst + head + body, sl.h_head + 4096, tail, hipMemcpyHostToDevice, d->copy_stream);
+            if (b0 < b1) {
+                if (hipHostRegister((void *)b0, (size_t)(b1 - b0), hipHostRegisterPortable) == hipSuccess) pinned.push_back((void *)b0);
+                else (void)hipGetLastError();
+                const uintptr_t body_end = last ? b1 : s1;           /* the copy stops at the group's data */
+                const size_t body = (size_t)(body_end - b0), tail = (size_t)(s1 - body_end);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(dst + head, (const void *)b0, body, hipMemcpyHostToDevice, d->copy_stream);
+                if (e == hipSuccess && tail) {
+                    memcpy(sl.h_head + 4096, (const void *)body_end, tail);
+                    e = hipMemcpyAsync(dst + head + body, sl.h_head + 4096, tail, hipMemcpyHostToDevice, d->copy_stream);
+                }
+            } else if (head_end < s1 && e == hipSuccess) {
+                /* less than a page left, beyond every registered block */
+                e = hipMemcpyAsync(dst + head, (const void *)head_end, (size_t)(s1 - head_end), hipMemcpyHostToDevice, d->copy_stream);
             }
-        } else {
-            e = hipMemcpyAsync(sl.llr.p, src, bytes, hipMemcpyHostToDevice, d->copy_stream);
         }
         if (e == hipSuccess) e = hipEventRecord(sl.h2d_done, d->copy_stream);
         if (e != hipSuccess) return fail(LDPC_ERR_HIP, "host-to-device staging: %s", hipGetErrorString(e));

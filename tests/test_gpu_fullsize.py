@@ -286,8 +286,9 @@ def test_bg1_layered_at_its_full_batch_of_8192(built):
 
 def test_rate_910_fp16_early_termination_at_its_full_batch_of_4096(built):
     """BASELINE.json configs[4] at its real size: DVB-S2-profile (64800, 58320), fp16 message storage,
-    early termination with host polling and tail compaction, batch 4096.  Iteration counts of ALL
-    frames and all bytes equal an unpolled, uncompacted run; 264 frames (the first tile + 8 scattered
+    early termination with host polling and tail compaction -- and without polling, with the device-side
+    hand-over -- batch 4096.  Iteration counts of ALL frames and all bytes equal an unpolled,
+    uncompacted run; 264 frames (the first tile + 8 scattered
     ones, the last included) equal the oracle's fp16-message min-sum (frames decoded in threads)."""
     N2, K2 = 64800, 58320
     rows, cols = codes.dvbs2_profile_edges(N2, K2)
@@ -308,6 +309,14 @@ def test_rate_910_fp16_early_termination_at_its_full_batch_of_4096(built):
     dec.close()
     assert np.array_equal(iters, it_ref) and np.array_equal(out, out_ref)
     assert iters[hard_idx].min() > np.delete(iters, hard_idx).max()                    # the premise: they ran on alone
+    # the asynchronous form: no polling, hand-over decided on the device (overflow tiles), then again
+    # with the idle hint of the first call
+    adec = L.Decoder(g, K2, max_batch=B, algo="ms", max_iter=50, msg_dtype="f16", poll_interval=0)
+    for _ in range(2):
+        out_a, it_a = adec.decode(y)
+        assert np.array_equal(it_a, it_ref) and np.array_equal(out_a, out_ref)
+        assert adec.stats()["frames_converged"] == st_ref["frames_converged"]
+    adec.close()
     assert st["frames_converged"] == st_ref["frames_converged"] >= int((iters < 50).sum())
     pick = np.r_[np.arange(256), [1300, 2047, 2048, 2222, 3000, 3839, 3840, 4095]]
     kb = K2 // 8
