@@ -22,7 +22,7 @@ Prints ONE JSON line (rank 0): metric/value/unit (whole-job Mbit/s), ms_per_step
 `roofline` for the dominant kernel (HIP-event time on the launch stream, live) and, at
 N = 1, `cpu_baseline` (the oracle's restatement of the reference's CPU decoder,
 MyLdpc.cpp:684-784, on a bounded sample), `extra` (BASELINE.json configs[3] and [4] at
-their full batch sizes) and `host_path` (the reference's own signature: host buffers in,
+their full batch sizes), `ber` (BER @ SNR points, the other half of BASELINE's metric) and `host_path` (the reference's own signature: host buffers in,
 host buffers out, PCIe included).
 """
 import argparse
@@ -156,6 +156,38 @@ def host_path(g, groups=3, B=BATCH_PER_GPU):
             "what": "ldpc_decode (Coder::decode's signature): %d frames from pageable host memory in %d groups of %d, "
                     "sum-product fp32, %d iterations at full work, packed bytes back in host memory; H2D of group "
                     "k+1 and D2H of group k-1 overlap the decode of group k" % (frames, groups, B, ITERS)}
+
+
+def ber_points(g, B=BATCH_PER_GPU):
+    """BER @ SNR on the headline code, reference convention (Test.cpp:56-57: BPSK +-1, sd =
+    10^(-SNR_dB/20)), all-zero codeword, channel and error count on the GPU: one batch per point."""
+    import torch
+    import myldpccppapi_amd as L
+    from myldpccppapi_amd import channel
+    pts = []
+    y = torch.empty((B, N_CODE), dtype=torch.float32, device="cuda")
+    out = torch.empty(L.out_bytes(K_CODE, B), dtype=torch.uint8, device="cuda")
+    it = torch.empty(B, dtype=torch.int32, device="cuda")
+    for algo, snrs in (("sp", (3.0, 4.0)), ("ms", (1.5, 1.7))):
+        dec = L.Decoder(g, K_CODE, max_batch=B, algo=algo, max_iter=ITERS, llr_scale=8.0, early_term=True, poll_interval=2)
+        for snr in snrs:
+            sd = 10.0 ** (-snr / 20.0)
+            channel.awgn_device(N_CODE, 0, B, sd, seed=SEED + 1, out=y)
+            t0 = time.perf_counter()
+            dec.decode_device(y.data_ptr(), B, out.data_ptr(), out.numel(), it.data_ptr(), None)
+            bit_err, byte_err, frame_err = channel.count_errors_device(out, None, B)
+            dt = time.perf_counter() - t0
+            pts.append({"algo": algo, "snr_db": snr, "sd": round(sd, 4), "frames": B, "info_bits": B * K_CODE,
+                        "bit_errors": bit_err, "ber": bit_err / (B * K_CODE), "byte_errors": byte_err,
+                        "fer": frame_err / B, "avg_iterations": round(float(it.float().mean()), 2),
+                        "decode_mbit_s": round(B * K_CODE / dt / 1e6, 1)})
+        dec.close()
+    del y, out, it
+    torch.cuda.empty_cache()
+    return {"code": "DVB-S2-PROFILE surrogate (64800,32400) -- the standard's structure from a seeded table, not "
+                    "its Annex B addresses: error rates are this table's, not DVB-S2's",
+            "max_iter": ITERS, "note": "sp = the reference's probability-domain decoder with its fixed exp(8 y) scale "
+            "(decodeCL.c:9); ms = flooding min-sum (decodeCPU's arithmetic)", "points": pts}
 
 
 def cpu_baseline(rows, cols, seconds_budget=20.0, gpu_graph=None, gpu_y=None):
@@ -446,6 +478,10 @@ def main():
                 except Exception as e:      # an extra point must never cost the headline line
                     extra[key] = {"error": repr(e)}
             res["extra"] = extra
+            try:
+                res["ber"] = ber_points(g)
+            except Exception as e:
+                res["ber"] = {"error": repr(e)}
             try:
                 res["host_path"] = host_path(g)
             except Exception as e:

@@ -260,6 +260,8 @@ struct ldpc_decoder {
     int tune_link_deep = 0;
     ldpc::Tune tune;                    /* cfg.tune_* unpacked (tune.hpp) */
     int tune_link_narrow = 1;           /* 0: wide linked check kernel */
+    bool link_calibrated = false;       /* narrow / wide chosen by timing both at creation */
+    float link_cal_ms[2] = {0, 0};      /* what the calibration measured: [0] wide, [1] narrow (per launch) */
     int link_rpw = 16;                  /* rows per wave of the fused check kernel; 0 = fusion off */
     VarFn var_fn[ldpc::kMaxUnrolledDegree + 1] = {};
 
@@ -825,6 +827,56 @@ int setup_flooding(ldpc_decoder *d, const ldpc_graph *g, size_t TF)
     return plan_launches(d);
 }
 
+/* The column-fused check kernel exists in wide waves (V values per lane, 114 VGPRs) and in narrow
+ * waves (1 value per lane, 48 VGPRs).  Which one is faster is a property of the box and its power
+ * state, not of the code: round 1 found narrow ahead by 2 % on its slow boxes, round 2's boxes run
+ * wide 10-17 % faster (profiles/r02_ab_link_wide.txt).  Unless the caller fixes the choice
+ * (LDPC_TUNE_LINK_NARROW), a decoder with several tiles therefore times both on its own arrays when
+ * it is created -- interleaved launches, a few milliseconds -- and keeps the faster.  The arrays hold
+ * zeros, which the first decode overwrites; results do not depend on the choice (the tests run both). */
+template <int V> int calibrate_link(ldpc_decoder *d)
+{
+    using namespace ldpc;
+    RowClass *rcp = nullptr;
+    for (auto &rc : d->row_classes) if (rc.linked) rcp = &rc;
+    if (!rcp || !d->link_fn[rcp->degree] || !d->link_narrow_fn[rcp->degree]) return LDPC_OK;
+    RowClass &rc = *rcp;
+    const int tiles = d->T;
+    hipStream_t s = d->stream;
+    HIP_TRY(hipMemsetAsync(d->Q.p, 0, d->Q.n, s));
+    HIP_TRY(hipMemsetAsync(d->chan.p, 0, d->chan.n, s));
+    HIP_TRY(hipMemsetAsync(d->done.p, 0, d->done.n * sizeof(uint64_t), s));
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    HIP_TRY(hipEventCreate(&ev[0]));
+    HIP_TRY(hipEventCreate(&ev[1]));
+    float best[2] = {1e30f, 1e30f};
+    hipError_t err = hipSuccess;
+    for (int rep = 0; rep < 4 && err == hipSuccess; ++rep) {
+        for (int nar = 0; nar < 2 && err == hipSuccess; ++nar) {
+            CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, d->link_rpw, rc.degree, TailRef{nullptr, 0, 0}};
+            LinkArgs lk{rc.link_col.p, rc.link_pos.p, d->chan.p, d->Q.p, d->hard.p, d->N, 1, 0, nullptr, nullptr, 0, 0};
+            const int waves = ((rc.count + d->link_rpw - 1) / d->link_rpw) * (nar ? V : 1);
+            lk.link_blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+            err = hipEventRecord(ev[0], s);
+            (nar ? d->link_narrow_fn : d->link_fn)[rc.degree]<<<dim3(lk.link_blocks, tiles), kBlock, 0, s>>>(a, lk);
+            if (err == hipSuccess) err = hipEventRecord(ev[1], s);
+            if (err == hipSuccess) err = hipEventSynchronize(ev[1]);
+            float ms = 0;
+            if (err == hipSuccess) err = hipEventElapsedTime(&ms, ev[0], ev[1]);
+            if (err == hipSuccess && rep > 0 && ms < best[nar]) best[nar] = ms;      /* rep 0 warms up */
+        }
+    }
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    if (err != hipSuccess) return fail(LDPC_ERR_HIP, "link calibration: %s", hipGetErrorString(err));
+    HIP_TRY(hipGetLastError());
+    d->link_cal_ms[0] = best[0];
+    d->link_cal_ms[1] = best[1];
+    d->tune_link_narrow = best[1] <= best[0] ? 1 : 0;
+    d->link_calibrated = true;
+    return LDPC_OK;
+}
+
 }  // namespace
 
 /* ================================================================== C ABI */
@@ -1096,6 +1148,11 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
         if (!d->use_fused) {
             int rc = setup_flooding(d, g, TF);
             if (rc) return rc;
+            /* narrow or wide column-fused check kernel: measured here unless the caller says which */
+            if (tune.link_narrow == 0 && !tune.link_deep && d->T >= 4 && !t_creating_child) {
+                rc = d->V == 1 ? calibrate_link<1>(d) : d->V == 2 ? calibrate_link<2>(d) : calibrate_link<4>(d);
+                if (rc) return rc;
+            }
             if (d->tail_enabled) {
                 HIP_TRY(d->tail_state.alloc(4));
                 HIP_TRY(d->tail_map.alloc((size_t)d->TO * d->F));
