@@ -121,7 +121,9 @@ enum ldpc_tune_field {
     LDPC_TUNE_LDSP = 2,         /* record kernels: posteriors in LDS, check records in cache        */
     LDPC_TUNE_LDSP_EXT = 4,     /* single-layer columns travel with the records (off: all in LDS)   */
     LDPC_TUNE_LDSP_PACK = 6,    /* several frames per wave for circulants of <= 32 rows             */
-    LDPC_TUNE_LINK_NARROW = 8,  /* column-fused check kernel in narrow waves (default on)           */
+    LDPC_TUNE_LINK_NARROW = 8,  /* column-fused check kernel in narrow waves (1 value per lane) or wide
+                                   (V per lane); default: both -- and LINK_HALF -- are timed when a
+                                   decoder of >= 4 tiles is created and the fastest is kept          */
     LDPC_TUNE_CHECK_WIDE = 10,  /* check kernels move V floats per lane (default off)               */
     LDPC_TUNE_SYN_XCD = 12,     /* XCD-aware syndrome grid (default on)                             */
     LDPC_TUNE_FUSED_PACK = 14,  /* fused layered kernel: several frames per wave (default on)       */
@@ -129,7 +131,8 @@ enum ldpc_tune_field {
     LDPC_TUNE_DEVICE_TAIL = 18, /* device-side early exit + tail compaction without host polling
                                    (default: on when early_term && poll_interval == 0)              */
     LDPC_TUNE_MERGE = 20,       /* degree classes of one bucket share a launch (default on)         */
-    LDPC_TUNE_LINK_DEEP = 22    /* column-fused check kernel requests its inputs two rows ahead     */
+    LDPC_TUNE_LINK_DEEP = 22,   /* column-fused check kernel requests its inputs two rows ahead     */
+    LDPC_TUNE_LINK_HALF = 24    /* column-fused check kernel with 2 values per lane (tiles of 256)  */
 };
 #define LDPC_TUNE_ON(field) (1 << (field))
 #define LDPC_TUNE_OFF(field) (2 << (field))

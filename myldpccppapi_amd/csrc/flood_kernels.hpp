@@ -585,8 +585,14 @@ __device__ __forceinline__ void link_extra_rows(const CheckArgs &a, const LinkAr
     check_row_generic<ALGO, V, T>(Qt, Rt, g.extra_e0[w], g.extra_deg[w]);
 }
 
+/* build-time experiment hook: -DLDPC_LINK_WIDE_WAVES=n asks the compiler for n waves per SIMD */
+#ifdef LDPC_LINK_WIDE_WAVES
+#define LDPC_LINK_WIDE_ATTR __attribute__((amdgpu_waves_per_eu(LDPC_LINK_WIDE_WAVES, LDPC_LINK_WIDE_WAVES)))
+#else
+#define LDPC_LINK_WIDE_ATTR
+#endif
 template <int ALGO, int D, int V, typename T>
-__global__ __launch_bounds__(kBlock) void check_link_kernel(const CheckArgs a, const LinkArgs g)
+__global__ __launch_bounds__(kBlock) LDPC_LINK_WIDE_ATTR void check_link_kernel(const CheckArgs a, const LinkArgs g)
 {
     constexpr size_t F = 64 * V;
     const int lane = threadIdx.x & 63;
@@ -727,45 +733,50 @@ template <int V> __device__ __forceinline__ uint64_t compress_stride(uint64_t x)
  * sub-wave j holds frames 64j..64j+63 of the tile, i.e. the 64/V-bit field [j*64/V, (j+1)*64/V)
  * of each of the V mask words (bit l of word v = frame V*l+v) -- written as that field alone
  * (16-bit stores at V = 4), no atomics: the fields of different sub-waves are disjoint. */
-template <int ALGO, int D, int V, typename T>
+template <int ALGO, int D, int V, typename T, int W = 1>
 __global__ __launch_bounds__(kBlock) void check_link_narrow_kernel(const CheckArgs a, const LinkArgs g)
 {
+    /* W values per lane: V / W sub-waves cover a row's 64*V-frame segment (W = 1: the narrow kernel;
+     * W = 2 at V = 4: 8 bytes per lane, half the registers of the wide kernel at twice its occupancy). */
     constexpr size_t F = 64 * V;
-    constexpr int FB = 64 / V;                       /* bits per field */
+    constexpr int SUBS = V / W;                      /* sub-waves per row chunk */
+    constexpr int FB = 64 / SUBS;                    /* bits per field */
     const int lane = threadIdx.x & 63;
     const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
     if (tile < 0) return;
     if ((int)blockIdx.x >= g.link_blocks) { link_extra_rows<ALGO, V, T>(a, g, tile); return; }
     const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
-    const int sub = wave % V;
-    const int r_begin = (wave / V) * a.rows_per_wave;
+    const int sub = wave % SUBS;
+    const int r_begin = (wave / SUBS) * a.rows_per_wave;
     const int r_end = min(r_begin + a.rows_per_wave, a.n_rows);
-    const size_t lane_off = (size_t)sub * 64 + lane;
+    const size_t lane_off = (size_t)sub * 64 * W + (size_t)lane * W;
     const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + lane_off;
     T *Qwt = static_cast<T *>(g.Qw) + (size_t)tile * (size_t)a.E * F + lane_off;
     T *Rt = static_cast<T *>(a.R) + (size_t)tile * (size_t)a.E * F + lane_off;
     const T *chan_t = static_cast<const T *>(g.chan) + (size_t)tile * (size_t)g.N * F + lane_off;
-    /* this lane's frame 64*sub + lane = V*l' + v'  ->  word v' = lane % V, bit sub*FB + lane / V */
-    const int my_word = lane % V, my_bit = lane / V;
+    /* this lane's value w is frame 64*W*sub + W*lane + w of the tile = V*l' + v'
+     *   ->  word v' = (W*lane + w) % V, bit sub*FB + (W*lane + w) / V */
     uint8_t *hard_b = reinterpret_cast<uint8_t *>(g.hard + (size_t)tile * (size_t)g.N * V) + (size_t)sub * (FB / 8);
     /* frozen frames of this sub-wave, per word (lanes 0..V-1 keep the field of word `lane`) */
     const uint64_t frozen_field = (a.done[(size_t)tile * V + (lane < V ? lane : 0)] >> (sub * FB)) &
-                                  (FB == 64 ? ~0ull : ((1ull << FB) - 1ull));
+                                  (FB == 64 ? ~0ull : ((1ull << (FB & 63)) - 1ull));
 
     auto load_field = [&](int col, int word) -> uint64_t {
         const uint8_t *p = hard_b + ((size_t)col * V + word) * 8;
-        if (V == 1) return *reinterpret_cast<const uint64_t *>(p);
-        if (V == 2) return *reinterpret_cast<const uint32_t *>(p);
+        if (FB == 64) return *reinterpret_cast<const uint64_t *>(p);
+        if (FB == 32) return *reinterpret_cast<const uint32_t *>(p);
         return *reinterpret_cast<const uint16_t *>(p);
     };
 
     int pend_col = -1, pend_edge = 0, pend_kb = 0;
-    float pend_r = 0.0f;
-    float x[D];
+    float pend_r[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) pend_r[w] = 0.0f;
+    float x[D][W];
     if (r_begin < r_end) {
         const int e0 = a.cls_e0[r_begin];
 #pragma unroll
-        for (int k = 0; k < D; ++k) { float t[1]; vload<1>(t, Qt + (size_t)(e0 + k) * F); x[k] = t[0]; }
+        for (int k = 0; k < D; ++k) vload<W>(x[k], Qt + (size_t)(e0 + k) * F);
     }
     for (int r = r_begin; r < r_end; ++r) {
         const int e0 = a.cls_e0[r];
@@ -773,70 +784,86 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow_kernel(const CheckAr
         const int pos = g.link_pos[r];
         const int ka = next_col >= 0 ? (pos & 255) : -1;
         const int kb = pend_col >= 0 ? pend_kb : -1;
-        float ch[1] = {0.0f};
-        uint64_t old_mine = 0;
-        if (pend_col >= 0) {
-            vload<1>(ch, chan_t + (size_t)pend_col * F);
-            old_mine = load_field(pend_col, my_word);
-        }
-        float xx[D][1], out[D][1];
+        float ch[W];
+        uint64_t old_mine[W];
 #pragma unroll
-        for (int k = 0; k < D; ++k) xx[k][0] = x[k];
-        if (ALGO == kAlgoSP) check_sp<D, 1>(xx, out); else check_ms<D, 1>(xx, out);
+        for (int w = 0; w < W; ++w) { ch[w] = 0.0f; old_mine[w] = 0; }
+        if (pend_col >= 0) {
+            vload<W>(ch, chan_t + (size_t)pend_col * F);
+#pragma unroll
+            for (int w = 0; w < W; ++w) old_mine[w] = load_field(pend_col, (W * lane + w) % V);
+        }
+        float out[D][W];
+        if (ALGO == kAlgoSP) check_sp<D, W>(x, out); else check_ms<D, W>(x, out);
         if (r + 1 < r_end) {
             const int e1 = a.cls_e0[r + 1];
 #pragma unroll
-            for (int k = 0; k < D; ++k) { float t[1]; vload<1>(t, Qt + (size_t)(e1 + k) * F); x[k] = t[0]; }
+            for (int k = 0; k < D; ++k) vload<W>(x[k], Qt + (size_t)(e1 + k) * F);
         }
 #pragma unroll
         for (int k = 0; k < D; ++k)
-            if ((k != ka && k != kb) || g.store_all) vstore<1>(Rt + (size_t)(e0 + k) * F, out[k]);
+            if ((k != ka && k != kb) || g.store_all) vstore<W>(Rt + (size_t)(e0 + k) * F, out[k]);
 
         if (pend_col >= 0) {
-            float rr[2][1], q[2][1];
-            rr[0][0] = pend_r;
-            float t = out[0][0];
+            float rr[2][W], q[2][W];
 #pragma unroll
-            for (int k = 1; k < D; ++k) t = (k == kb) ? out[k][0] : t;
-            rr[1][0] = t;
-            bool bit;
-            if (ALGO == kAlgoSP) {
-                float f0[1], f1[1];
-                var_sp<2, 1>(ch, rr, q, f0, f1);
-                const bool oldb = (old_mine >> my_bit) & 1ull;
-                bit = (f0[0] > f1[0]) ? false : ((f0[0] < f1[0]) ? true : oldb);
-            } else {
-                float p = ch[0];
-                p += rr[0][0];
-                p += rr[1][0];
-                q[0][0] = p - rr[0][0];
-                q[1][0] = p - rr[1][0];
-                bit = !(p > 0.0f);
+            for (int w = 0; w < W; ++w) {
+                rr[0][w] = pend_r[w];
+                float t = out[0][w];
+#pragma unroll
+                for (int k = 1; k < D; ++k) t = (k == kb) ? out[k][w] : t;
+                rr[1][w] = t;
             }
-            const uint64_t ballot = __ballot(bit);
+            uint64_t ballot[W];
+            if (ALGO == kAlgoSP) {
+                float f0[W], f1[W];
+                var_sp<2, W>(ch, rr, q, f0, f1);
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    const bool oldb = (old_mine[w] >> ((W * lane + w) / V)) & 1ull;
+                    const bool bit = (f0[w] > f1[w]) ? false : ((f0[w] < f1[w]) ? true : oldb);
+                    ballot[w] = __ballot(bit);
+                }
+            } else {
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    float p = ch[w];
+                    p += rr[0][w];
+                    p += rr[1][w];
+                    q[0][w] = p - rr[0][w];
+                    q[1][w] = p - rr[1][w];
+                    ballot[w] = __ballot(!(p > 0.0f));
+                }
+            }
             if (lane < V) {
-                /* field of word `lane`: the bits of lanes lane, lane+V, lane+2V, ... */
-                const uint64_t nf = compress_stride<V>(ballot >> lane);
+                /* field of word `lane` = W*j + w: value w of the lanes j, j + SUBS, j + 2*SUBS, ... */
+                uint64_t bw = ballot[0];
+#pragma unroll
+                for (int w = 1; w < W; ++w) bw = (lane % W == w) ? ballot[w] : bw;
+                const uint64_t nf = compress_stride<SUBS>(bw >> (lane / W));
                 const uint64_t of = load_field(pend_col, lane);
                 const uint64_t res = (of & frozen_field) | (nf & ~frozen_field);
                 uint8_t *p = hard_b + ((size_t)pend_col * V + lane) * 8;
-                if (V == 1) *reinterpret_cast<uint64_t *>(p) = res;
-                else if (V == 2) *reinterpret_cast<uint32_t *>(p) = (uint32_t)res;
+                if (FB == 64) *reinterpret_cast<uint64_t *>(p) = res;
+                else if (FB == 32) *reinterpret_cast<uint32_t *>(p) = (uint32_t)res;
                 else *reinterpret_cast<uint16_t *>(p) = (uint16_t)res;
             }
             if (g.write_q) {
-                vstore<1>(Qwt + (size_t)pend_edge * F, q[0]);
-                vstore<1>(Qwt + (size_t)(e0 + kb) * F, q[1]);
+                vstore<W>(Qwt + (size_t)pend_edge * F, q[0]);
+                vstore<W>(Qwt + (size_t)(e0 + kb) * F, q[1]);
             }
         }
         pend_col = next_col;
         if (next_col >= 0) {
             pend_edge = e0 + ka;
             pend_kb = (pos >> 8) & 255;
-            float t = out[0][0];
 #pragma unroll
-            for (int k = 1; k < D; ++k) t = (k == ka) ? out[k][0] : t;
-            pend_r = t;
+            for (int w = 0; w < W; ++w) {
+                float t = out[0][w];
+#pragma unroll
+                for (int k = 1; k < D; ++k) t = (k == ka) ? out[k][w] : t;
+                pend_r[w] = t;
+            }
         }
     }
 }

@@ -146,17 +146,24 @@ template <int V, typename T> struct CheckTableMS<V, T, ldpc::kMaxUnrolledDegree>
 };
 
 using LinkFn = void (*)(const ldpc::CheckArgs, const ldpc::LinkArgs);
+template <int ALGO, int V, typename T, int D> struct LinkHalf {      /* 2 values per lane: V = 4 only */
+    static LinkFn get() { return nullptr; }
+};
+template <int ALGO, typename T, int D> struct LinkHalf<ALGO, 4, T, D> {
+    static LinkFn get() { return ldpc::check_link_narrow_kernel<ALGO, D, 4, T, 2>; }
+};
 template <int ALGO, int V, typename T, int D> struct LinkTable {
-    static void fill(LinkFn *t, LinkFn *tn, LinkFn *td)
+    static void fill(LinkFn *t, LinkFn *tn, LinkFn *td, LinkFn *th)
     {
         t[D] = ldpc::check_link_kernel<ALGO, D, V, T>;
         tn[D] = ldpc::check_link_narrow_kernel<ALGO, D, V, T>;
         td[D] = ldpc::check_link_narrow2_kernel<ALGO, D, V, T>;
-        LinkTable<ALGO, V, T, D - 1>::fill(t, tn, td);
+        th[D] = LinkHalf<ALGO, V, T, D>::get();
+        LinkTable<ALGO, V, T, D - 1>::fill(t, tn, td, th);
     }
 };
 template <int ALGO, int V, typename T> struct LinkTable<ALGO, V, T, 1> {
-    static void fill(LinkFn *, LinkFn *, LinkFn *) {}
+    static void fill(LinkFn *, LinkFn *, LinkFn *, LinkFn *) {}
 };
 
 /* group launches (several degree classes of a bucket in one launch, flood_kernels.hpp) */
@@ -257,11 +264,12 @@ struct ldpc_decoder {
     LinkFn link_fn[ldpc::kMaxUnrolledDegree + 1] = {};        /* wide waves */
     LinkFn link_narrow_fn[ldpc::kMaxUnrolledDegree + 1] = {}; /* narrow waves */
     LinkFn link_deep_fn[ldpc::kMaxUnrolledDegree + 1] = {};   /* narrow waves, inputs two rows ahead */
+    LinkFn link_half_fn[ldpc::kMaxUnrolledDegree + 1] = {};   /* 2 values per lane (V = 4) */
     int tune_link_deep = 0;
     ldpc::Tune tune;                    /* cfg.tune_* unpacked (tune.hpp) */
-    int tune_link_narrow = 1;           /* 0: wide linked check kernel */
-    bool link_calibrated = false;       /* narrow / wide chosen by timing both at creation */
-    float link_cal_ms[2] = {0, 0};      /* what the calibration measured: [0] wide, [1] narrow (per launch) */
+    int tune_link_narrow = 1;           /* linked check kernel: 0 wide (V values per lane), 1 narrow (1), 2 half (2) */
+    bool link_calibrated = false;       /* chosen by timing the candidates at creation */
+    float link_cal_ms[3] = {0, 0, 0};   /* what the calibration measured per launch: [0] wide, [1] narrow, [2] half */
     int link_rpw = 16;                  /* rows per wave of the fused check kernel; 0 = fusion off */
     VarFn var_fn[ldpc::kMaxUnrolledDegree + 1] = {};
 
@@ -516,11 +524,12 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             LinkArgs lk{rc.link_col.p, rc.link_pos.p, d->chan.p, d->Q.p, d->hard.p, d->N,
                         (it < max_iter) ? 1 : 0, d->tap_iter ? 1 : 0, d->extra_e0.p, d->extra_deg.p, d->n_extra, 0};
             a.rows_per_wave = d->link_rpw;
-            const bool nar = d->tune_link_narrow != 0;
-            const int waves = ((rc.count + d->link_rpw - 1) / d->link_rpw) * (nar ? V : 1);
+            const int variant = (d->tune_link_narrow == 2 && !d->link_half_fn[rc.degree]) ? 1 : d->tune_link_narrow;
+            const int waves = ((rc.count + d->link_rpw - 1) / d->link_rpw) * (variant == 1 ? V : variant == 2 ? V / 2 : 1);
             lk.link_blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
             dim3 grid(lk.link_blocks + (d->n_extra + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
-            (nar ? (d->tune_link_deep ? d->link_deep_fn : d->link_narrow_fn) : d->link_fn)[rc.degree]<<<grid, kBlock, 0, s>>>(a, lk);
+            (variant == 2 ? d->link_half_fn : variant == 1 ? (d->tune_link_deep ? d->link_deep_fn : d->link_narrow_fn) : d->link_fn)
+                [rc.degree]<<<grid, kBlock, 0, s>>>(a, lk);
             HIP_TRY(span_end(d, s));
         }
         for (auto &g : d->check_groups) {
@@ -804,7 +813,7 @@ int setup_flooding(ldpc_decoder *d, const ldpc_graph *g, size_t TF)
 #define LDPC_FILL(ALGO, TYPE, VV)                                                      \
     do {                                                                               \
         FloodTable<ALGO, VV, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn); \
-        LinkTable<ALGO, VV, TYPE, DM>::fill(d->link_fn, d->link_narrow_fn, d->link_deep_fn); \
+        LinkTable<ALGO, VV, TYPE, DM>::fill(d->link_fn, d->link_narrow_fn, d->link_deep_fn, d->link_half_fn); \
         GroupTable<ALGO, VV, TYPE>::fill(d->check_group_fn, d->var_group_fn);          \
         d->init_fn = pick_init<ALGO, TYPE>(VV);                                        \
         if (ALGO == kAlgoMS) {   /* min-sum rows of degree 17..32: narrow unrolled kernels */ \
@@ -849,16 +858,17 @@ template <int V> int calibrate_link(ldpc_decoder *d)
     hipEvent_t ev[2] = {nullptr, nullptr};
     HIP_TRY(hipEventCreate(&ev[0]));
     HIP_TRY(hipEventCreate(&ev[1]));
-    float best[2] = {1e30f, 1e30f};
+    float best[3] = {1e30f, 1e30f, 1e30f};
+    const int candidates = d->link_half_fn[rc.degree] ? 3 : 2;
     hipError_t err = hipSuccess;
     for (int rep = 0; rep < 4 && err == hipSuccess; ++rep) {
-        for (int nar = 0; nar < 2 && err == hipSuccess; ++nar) {
+        for (int nar = 0; nar < candidates && err == hipSuccess; ++nar) {
             CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, d->link_rpw, rc.degree, TailRef{nullptr, 0, 0}};
             LinkArgs lk{rc.link_col.p, rc.link_pos.p, d->chan.p, d->Q.p, d->hard.p, d->N, 1, 0, nullptr, nullptr, 0, 0};
-            const int waves = ((rc.count + d->link_rpw - 1) / d->link_rpw) * (nar ? V : 1);
+            const int waves = ((rc.count + d->link_rpw - 1) / d->link_rpw) * (nar == 1 ? V : nar == 2 ? V / 2 : 1);
             lk.link_blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
             err = hipEventRecord(ev[0], s);
-            (nar ? d->link_narrow_fn : d->link_fn)[rc.degree]<<<dim3(lk.link_blocks, tiles), kBlock, 0, s>>>(a, lk);
+            (nar == 2 ? d->link_half_fn : nar == 1 ? d->link_narrow_fn : d->link_fn)[rc.degree]<<<dim3(lk.link_blocks, tiles), kBlock, 0, s>>>(a, lk);
             if (err == hipSuccess) err = hipEventRecord(ev[1], s);
             if (err == hipSuccess) err = hipEventSynchronize(ev[1]);
             float ms = 0;
@@ -870,9 +880,9 @@ template <int V> int calibrate_link(ldpc_decoder *d)
     (void)hipEventDestroy(ev[1]);
     if (err != hipSuccess) return fail(LDPC_ERR_HIP, "link calibration: %s", hipGetErrorString(err));
     HIP_TRY(hipGetLastError());
-    d->link_cal_ms[0] = best[0];
-    d->link_cal_ms[1] = best[1];
-    d->tune_link_narrow = best[1] <= best[0] ? 1 : 0;
+    int pick = 0;
+    for (int k = 0; k < candidates; ++k) { d->link_cal_ms[k] = best[k]; if (best[k] < best[pick]) pick = k; }
+    d->tune_link_narrow = pick;
     d->link_calibrated = true;
     return LDPC_OK;
 }
@@ -1032,7 +1042,7 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     d->tune_cpw = tune.cols_per_wave;
     d->tune_syn_xcd = ldpc::tune_pick(tune.syn_xcd, true);
     d->tune_check_wide = ldpc::tune_pick(tune.check_wide, false);
-    d->tune_link_narrow = ldpc::tune_pick(tune.link_narrow, true);
+    d->tune_link_narrow = ldpc::tune_pick(tune.link_half, false) ? 2 : (ldpc::tune_pick(tune.link_narrow, true) ? 1 : 0);
     d->tune_link_deep = ldpc::tune_pick(tune.link_deep, false);
     if (tune.link_rows) d->link_rpw = tune.link_rows < 0 ? 0 : tune.link_rows;
     d->V = pick_frames_per_lane(*cfg, g->max_row_deg, g->max_col_deg);
@@ -1149,7 +1159,7 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
             int rc = setup_flooding(d, g, TF);
             if (rc) return rc;
             /* narrow or wide column-fused check kernel: measured here unless the caller says which */
-            if (tune.link_narrow == 0 && !tune.link_deep && d->T >= 4 && !t_creating_child) {
+            if (tune.link_narrow == 0 && tune.link_half == 0 && !tune.link_deep && d->T >= 4 && !t_creating_child) {
                 rc = d->V == 1 ? calibrate_link<1>(d) : d->V == 2 ? calibrate_link<2>(d) : calibrate_link<4>(d);
                 if (rc) return rc;
             }
@@ -1588,7 +1598,8 @@ int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t ca
     HIP_TRY(hipSetDevice(d->cfg.device));
     HIP_TRY(hipEventSynchronize(d->ev_end));
     const char *phase_name[] = {"check_kernel", "var_kernel", "layer_kernel", "other",
-                                d->tune_link_narrow ? "check_link_narrow_kernel" : "check_link_kernel"};
+                                d->tune_link_narrow == 2 ? "check_link_half_kernel"
+                                : d->tune_link_narrow ? "check_link_narrow_kernel" : "check_link_kernel"};
     static const char *algo_name_f32[] = {"sp", "ms", "layered", "ms_fused", "layered_host"};
     static const char *algo_name_f16[] = {"sp16", "ms16", "layered16", "ms_fused16", "layered_host16"};
     const char **algo_name = d->msg_size == 2 ? algo_name_f16 : algo_name_f32;

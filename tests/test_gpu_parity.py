@@ -354,23 +354,24 @@ def test_column_local_fusion_on_staircase_code(built, algo):
     og = oracle.Graph(rows, cols, N2 - K2, N2, K2)
     y = channel.awgn_frames(N2, 0, 70, 0.72 if algo == "ms" else 0.8, seed=14)
     want = oracle.decode(og, y, algo, max_iter=25, tap_iter=2)
-    for rpw, deep in ((8, False), (3, False), (-1, False), (16, True), (7, True), (2, True)):
+    for rpw, variant in ((8, {}), (3, {}), (-1, {}), (16, {"link_deep": True}), (7, {"link_deep": True}), (2, {"link_deep": True}),
+                         (8, {"link_narrow": False}), (5, {"link_half": True}), (16, {"link_half": True})):
         for V in (1, 4):
-            # deep: the fused check kernel with its inputs requested two rows ahead (check_link_narrow2_kernel)
+            # link_deep: inputs requested two rows ahead; link_narrow False: V values per lane; link_half: 2 per lane (V = 4)
             dec = L.Decoder(g, K2, max_batch=70, algo=algo, max_iter=25, frames_per_lane=V,
-                            tune={"link_rows": rpw, "link_deep": deep})
+                            tune=dict(variant, link_rows=rpw))
             out, iters = dec.decode(y)
-            assert np.array_equal(out, want["out"]) and np.array_equal(iters, want["iters"]), (rpw, V)
+            assert np.array_equal(out, want["out"]) and np.array_equal(iters, want["iters"]), (rpw, variant, V)
             dec.set_tap(2)
             dec.decode(y)
             run_q = np.nonzero(want["iters"] > 2)[0]
             Q = dec.dump(1, 70)
             if algo == "ms":
-                assert np.array_equal(Q[run_q], want["taps"]["q"][run_q], equal_nan=True), (rpw, V)
-                assert np.array_equal(dec.dump(0, 70)[run_q], want["taps"]["r"][run_q]), (rpw, V)
+                assert np.array_equal(Q[run_q], want["taps"]["q"][run_q], equal_nan=True), (rpw, variant, V)
+                assert np.array_equal(dec.dump(0, 70)[run_q], want["taps"]["r"][run_q]), (rpw, variant, V)
             else:
                 dq = want["taps"]["q0"] - want["taps"]["q1"]
-                assert np.array_equal(Q[run_q], dq[run_q], equal_nan=True), (rpw, V)
+                assert np.array_equal(Q[run_q], dq[run_q], equal_nan=True), (rpw, variant, V)
             dec.close()
 
 
