@@ -30,10 +30,11 @@ def short(name):
 
 def display(name):
     """check_kernel<0, 7, 4> -> check_kernel<sp,7,4> (the names bench.py prints)"""
-    m = re.match(r"(check_kernel|check_link_kernel|check_link_narrow_kernel|var_kernel)<(\d), (\d+), (\d)(?:, \d)?, (float|_Float16)>", name)
+    m = re.match(r"(check_kernel|check_link_kernel|check_link_narrow_kernel|check_link_narrow2_kernel|var_kernel)<(\d), (\d+), (\d)(?:, \d)?, (float|_Float16)(?:, (\d))?>", name)
     if m:
         algo = ("sp", "ms")[int(m.group(2))] + ("16" if m.group(5) != "float" else "")
-        return "%s<%s,%s,%s>" % (m.group(1), algo, m.group(3), m.group(4))
+        kern = "check_link_half_kernel" if (m.group(1) == "check_link_narrow_kernel" and m.group(6) == "2") else m.group(1)
+        return "%s<%s,%s,%s>" % (kern, algo, m.group(3), m.group(4))
     m = re.match(r"(check_group_kernel|var_group_kernel)<(\d), (\d), (float|_Float16), (\d+), (\d+)>", name)
     if m:
         algo = ("sp", "ms")[int(m.group(2))] + ("16" if m.group(4) != "float" else "")
