@@ -88,9 +88,13 @@ for case in range(max(4, cases // 6)):
     os.environ["LDPC_TUNE_FUSED"] = "0"
     os.environ["LDPC_TUNE_LDSP"] = "0"
     os.environ["LDPC_TUNE_COMPACT"] = str(int(rng.choice([512, 512, 64, 9])))
-    dec = L.Decoder(g, K, max_batch=B, algo=algo, max_iter=iters, poll_interval=int(rng.integers(1, 4)),
+    tune = L.capi.tune_from_env()
+    tune["merge"] = bool(rng.integers(0, 2))
+    devs = None if rng.random() < 0.6 else [0] * int(rng.integers(2, 4))
+    dec = L.Decoder(g, K, max_batch=B if devs is None else max(64, B // 3), algo=algo, max_iter=iters,
+                    poll_interval=int(rng.integers(0, 4)),
                     frames_per_lane=int(rng.choice([1, 2, 4])), msg_dtype="f16" if f16 else "f32",
-                    tune=L.capi.tune_from_env())
+                    tune=tune, devices=devs)
     out, it = dec.decode(y)
     good = np.array_equal(out, want["out"]) and np.array_equal(it, want["iters"])
     dec.close()
@@ -98,5 +102,47 @@ for case in range(max(4, cases // 6)):
         bad += 1
         print("MISMATCH streaming case", case, rate, N, B, algo, f16, iters, flush=True)
     print("streaming case %d ok: rate=%d N=%d B=%d %s%s iters=%d stragglers=%d" % (case, rate, N, B, algo, "16" if f16 else "", iters, ns), flush=True)
+# third phase: the streaming kernels on IRA (DVB-S2-profile) codes, where the column-fused check kernel
+# runs: every form of it (wide / narrow / half / deep), merged and per-class launches, host polling,
+# the device-side tail (large asynchronous batches, called twice: idle hint) and device lists
+import torch  # noqa: E402
+for case in range(max(6, cases // 4)):
+    N2, K2 = (12960, 6480) if case % 3 else (16200, 10800)
+    rows, cols = codes.dvbs2_profile_edges(N2, K2, profile=None if case % 3 else [(9, 5), (3, 25)])   # column degrees 9, 3, 2
+    M2 = N2 - K2
+    g = L.Graph(rows, cols, M2, N2)
+    og = oracle.Graph(rows, cols, M2, N2, K2)
+    big = case % 2 == 0
+    B = int(rng.integers(2100, 2600)) if big else int(rng.integers(65, 700))
+    algo = ("sp", "ms", "ms")[case % 3]
+    f16 = algo == "ms" and case % 2 == 1
+    iters = int(rng.integers(6, 22))
+    y = channel.awgn_frames(N2, 0, B, 0.62 if algo == "ms" else 0.5, seed=8000 + case)
+    ns = int(rng.integers(1, 70))
+    slow = rng.choice(B, ns, replace=False)
+    y[slow] = channel.awgn_frames(N2, 9000, ns, float(rng.uniform(0.95, 1.3)), seed=8500 + case)
+    from concurrent.futures import ThreadPoolExecutor
+    chunks = np.array_split(np.arange(B), 16)
+    with ThreadPoolExecutor(16) as ex:
+        parts = list(ex.map(lambda ix: oracle.decode(og, y[ix], algo, max_iter=iters, msg_f16=f16), chunks))
+    want_out = np.concatenate([p_["out"] for p_ in parts])
+    want_it = np.concatenate([p_["iters"] for p_ in parts])
+    variant = [{}, {"link_narrow": True}, {"link_narrow": False}, {"link_half": True}, {"link_deep": True}][int(rng.integers(0, 5))]
+    tune = dict(variant, merge=bool(rng.integers(0, 2)), link_rows=int(rng.choice([0, 3, 8, 16, 21])))
+    poll = 0 if big else int(rng.integers(0, 3))
+    devs = None if big or rng.random() < 0.5 else [0] * int(rng.integers(2, 4))
+    fpl = int(rng.choice([1, 2, 4]))
+    dec = L.Decoder(g, K2, max_batch=B if devs is None else max(64, B // 3), algo=algo, max_iter=iters, poll_interval=poll,
+                    frames_per_lane=fpl, msg_dtype="f16" if f16 else "f32", tune=tune, devices=devs)
+    good = True
+    for rep in range(2):
+        out, it = dec.decode(y)
+        good = good and np.array_equal(out, want_out) and np.array_equal(it, want_it)
+    dec.close()
+    if not good:
+        bad += 1
+        print("MISMATCH ira case", case, N2, B, algo, f16, iters, tune, poll, devs, fpl, flush=True)
+    print("ira case %d ok: N=%d B=%d %s%s iters=%d stragglers=%d tune=%s poll=%d devices=%s fpl=%d" % (
+        case, N2, B, algo, "16" if f16 else "", iters, ns, tune, poll, devs, fpl), flush=True)
 print("soak finished:", cases, "cases,", bad, "mismatches")
 sys.exit(1 if bad else 0)
