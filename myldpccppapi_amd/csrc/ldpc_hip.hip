@@ -296,6 +296,7 @@ struct ldpc_decoder {
     } slot[3];
     bool suppress_poll = false;
     int32_t *h_active = nullptr;        /* pinned */
+    uint8_t *h_bounce = nullptr;        /* pinned, 4 MiB: input blocks that could not be page-locked */
     /* tail compaction (flood_kernels.hpp): a V = 1, one-tile decoder that takes over the last running
      * frames of a polled, early-terminating decode */
     ldpc_decoder *child = nullptr;
@@ -345,6 +346,7 @@ struct ldpc_decoder {
         if (ev_begin) (void)hipEventDestroy(ev_begin);
         if (ev_end) (void)hipEventDestroy(ev_end);
         if (h_active) (void)hipHostFree(h_active);
+        if (h_bounce) (void)hipHostFree(h_bounce);
         if (h_summary) (void)hipHostFree(h_summary);
         if (ev_summary) (void)hipEventDestroy(ev_summary);
         for (auto &sl : slot) {
@@ -1315,9 +1317,22 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
     return LDPC_OK;
 }
 
-/* ldpc_decode on ONE device. */
+/* Has the caller page-locked this memory itself (hipHostMalloc, hipHostRegister, a framework's pinned
+ * allocator)?  Then it is locked as a whole, for longer than a decode call, and is copied from directly. */
+static bool caller_locked_memory(const void *p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) == hipSuccess) return at.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    return false;
+}
+
+/* ldpc_decode on ONE device.  pin_mode 0: decide here (lock the input when the call has several
+ * groups); 1: the caller runs several of these side by side on neighbouring ranges of one buffer
+ * (device list) -- every group is copied from pages this call has locked itself, never as a pageable
+ * source; 2: the caller's buffer is page-locked as a whole -- plain copies. */
 static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t *out_host,
-                       int64_t out_bytes, int32_t *iters)
+                       int64_t out_bytes, int32_t *iters, int pin_mode)
 {
     const int64_t total = ldpc_out_bytes(d->cfg.K, frames, d->cfg.pack_mode);
     HIP_TRY(hipSetDevice(d->cfg.device));
@@ -1340,7 +1355,7 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
         HIP_TRY(sl.iters.alloc((size_t)B));
         HIP_TRY(hipHostMalloc((void **)&sl.h_out, (size_t)stage_out, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc((void **)&sl.h_iters, (size_t)B * sizeof(int32_t), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void **)&sl.h_head, 2 * 4096, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&sl.h_head, 4 * 4096, hipHostMallocDefault));
         HIP_TRY(hipEventCreateWithFlags(&sl.h2d_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sl.all_done, hipEventDisableTiming));
     }
@@ -1354,21 +1369,38 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
         return LDPC_OK;
     };
     /* A copy from pageable memory waits for the device's other work (measured: 151 ms behind a
-     * 140 ms decode instead of 19 ms), so from the second group on the caller's pages are page-locked
-     * for the duration of the call: a true DMA that runs beside the previous group's kernels.
-     * Group k >= 1 owns the block from its first page boundary up to the next group's first page
-     * boundary -- the last group up to its LAST page boundary: blocks are whole pages inside this
-     * call's own byte range and page-disjoint.  No registered page is ever shared with memory that
-     * anybody copies as pageable (this call's group 0, or group 0 of the neighbouring frame range in
-     * another device's thread: the runtime would take such a source for pinned memory and read past
-     * the registered block -- a GPU memory fault, seen once).  Each block is registered just before
-     * its copy -- i.e. while the previous group decodes -- and all are released only after both
-     * streams have drained.  The bytes of a group before its first page boundary (and after the last
-     * group's last one) are read by the CPU into pinned scratch pages.  Group 0 is copied as it is:
-     * nothing of this call runs yet that it could overlap with.  A block that cannot be registered
-     * (already page-locked by the caller, or by another call decoding the same buffer) is copied
-     * pageable. */
+     * 140 ms decode instead of 19 ms), so a call of several groups page-locks the caller's input for
+     * its duration: a true DMA that runs beside the previous group's kernels.  The rule that keeps
+     * this safe: the GPU only ever reads (a) this library's own pinned scratch and (b) WHOLE pages
+     * that this call has registered itself and that lie strictly inside its own byte range.
+     * Group k owns the block from its first page boundary up to the next group's first page boundary
+     * (the last group: up to its last page boundary); blocks are page-disjoint, each is registered
+     * just before its copy -- i.e. while the previous group decodes -- and all are released only
+     * after both streams have drained.  The bytes of a group before its first page boundary (and after
+     * the last group's last one) are read by the CPU into pinned scratch pages.  No pageable copy is
+     * issued from a buffer that has registered pages, neither by this call nor -- with a device list --
+     * by the threads working on the neighbouring ranges: the runtime resolves a host pointer through
+     * its table of locked ranges, and a pageable source next to (or starting inside) somebody's
+     * locked block ended in GPU memory faults twice during round 2.  A block that cannot be
+     * registered (already page-locked by the caller) is copied as the runtime sees fit. */
     std::vector<void *> pinned;
+    const bool pin = pin_mode == 1 || (pin_mode == 0 && nslots > 1 && !caller_locked_memory(llr_host));
+    /* a block that cannot be locked goes through a pinned bounce buffer, chunk by chunk (slow, safe) */
+    auto bounce_copy = [&](uint8_t *dst, const uint8_t *src, size_t n) -> hipError_t {
+        constexpr size_t kChunk = (size_t)4 << 20;
+        if (!d->h_bounce) {
+            hipError_t e0 = hipHostMalloc((void **)&d->h_bounce, kChunk, hipHostMallocDefault);
+            if (e0 != hipSuccess) return e0;
+        }
+        for (size_t o = 0; o < n; o += kChunk) {
+            const size_t c = std::min(kChunk, n - o);
+            memcpy(d->h_bounce, src + o, c);
+            hipError_t e1 = hipMemcpyAsync(dst + o, d->h_bounce, c, hipMemcpyHostToDevice, d->copy_stream);
+            if (e1 == hipSuccess) e1 = hipStreamSynchronize(d->copy_stream);
+            if (e1 != hipSuccess) return e1;
+        }
+        return hipSuccess;
+    };
     int rc = LDPC_OK;
 #ifdef LDPC_TRACE_HOST
     const auto t_start = std::chrono::steady_clock::now();
@@ -1393,31 +1425,29 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
         const bool last = kk + 1 == ngroups;
         const uintptr_t b1 = last ? (s1 & ~(uintptr_t)4095) : ((s1 + 4095) & ~(uintptr_t)4095);   /* end of the block */
         uint8_t *dst = reinterpret_cast<uint8_t *>(sl.llr.p);
-        if (kk == 0) {
-            e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->copy_stream);
+        if (!pin) {
+            e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->copy_stream);      /* one group, nothing locked */
+        } else if (b0 >= b1) {
+            /* less than two pages in all: through the scratch */
+            memcpy(sl.h_head, src, bytes);
+            e = hipMemcpyAsync(dst, sl.h_head, bytes, hipMemcpyHostToDevice, d->copy_stream);
         } else {
-            /* the bytes before the first page boundary may share their page with the previous group's
-             * registered block: always through the scratch page, never as a pageable source */
-            const uintptr_t head_end = std::min(s1, b0);
-            const size_t head = (size_t)(head_end - s0);
+            const size_t head = (size_t)(b0 - s0);
             if (head) {
                 memcpy(sl.h_head, src, head);
                 e = hipMemcpyAsync(dst, sl.h_head, head, hipMemcpyHostToDevice, d->copy_stream);
             }
-            if (b0 < b1) {
-                if (hipHostRegister((void *)b0, (size_t)(b1 - b0), hipHostRegisterPortable) == hipSuccess) pinned.push_back((void *)b0);
-                else (void)hipGetLastError();
-                const uintptr_t body_end = last ? b1 : s1;           /* the copy stops at the group's data */
-                const size_t body = (size_t)(body_end - b0), tail = (size_t)(s1 - body_end);
-                if (e == hipSuccess)
-                    e = hipMemcpyAsync(dst + head, (const void *)b0, body, hipMemcpyHostToDevice, d->copy_stream);
-                if (e == hipSuccess && tail) {
-                    memcpy(sl.h_head + 4096, (const void *)body_end, tail);
-                    e = hipMemcpyAsync(dst + head + body, sl.h_head + 4096, tail, hipMemcpyHostToDevice, d->copy_stream);
-                }
-            } else if (head_end < s1 && e == hipSuccess) {
-                /* less than a page left, beyond every registered block */
-                e = hipMemcpyAsync(dst + head, (const void *)head_end, (size_t)(s1 - head_end), hipMemcpyHostToDevice, d->copy_stream);
+            const bool locked = hipHostRegister((void *)b0, (size_t)(b1 - b0), hipHostRegisterPortable) == hipSuccess;
+            if (locked) pinned.push_back((void *)b0);
+            else (void)hipGetLastError();
+            const uintptr_t body_end = last ? b1 : s1;               /* the copy stops at the group's data */
+            const size_t body = (size_t)(body_end - b0), tail = (size_t)(s1 - body_end);
+            if (e == hipSuccess)
+                e = locked ? hipMemcpyAsync(dst + head, (const void *)b0, body, hipMemcpyHostToDevice, d->copy_stream)
+                           : bounce_copy(dst + head, (const uint8_t *)b0, body);
+            if (e == hipSuccess && tail) {
+                memcpy(sl.h_head + 4096, (const void *)body_end, tail);
+                e = hipMemcpyAsync(dst + head + body, sl.h_head + 4096, tail, hipMemcpyHostToDevice, d->copy_stream);
             }
         }
         if (e == hipSuccess) e = hipEventRecord(sl.h2d_done, d->copy_stream);
@@ -1488,7 +1518,7 @@ int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
     if (frames == 0) return LDPC_OK;
     if (!llr_host || !out_host) return fail(LDPC_ERR_ARG, "llr/out is NULL");
     if (out_bytes < 0) return fail(LDPC_ERR_ARG, "out_bytes < 0");
-    if (d->shards.empty()) return decode_host(d, llr_host, frames, out_host, out_bytes, iters);
+    if (d->shards.empty()) return decode_host(d, llr_host, frames, out_host, out_bytes, iters, 0);
 
     /* several devices: one host thread per device decodes a contiguous frame range */
     const int n = (int)d->shards.size();
@@ -1500,7 +1530,8 @@ int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
         if (rc) return rc;
         active += hi[i] > lo[i];
     }
-    (void)active;
+    /* asked once, before any thread locks anything */
+    const int pin_mode = (n > 1 && active > 1) ? (caller_locked_memory(llr_host) ? 2 : 1) : 0;
     std::vector<int> rcs((size_t)n, LDPC_OK);
     std::vector<std::string> errs((size_t)n);
     auto work = [&](int i) {
@@ -1511,7 +1542,7 @@ int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
         const int64_t room = std::max<int64_t>(0, out_bytes - base);
         rcs[i] = decode_host(sh, llr_host + (size_t)lo[i] * d->N, hi[i] - lo[i], out_host + base,
                              std::min(room, ldpc_out_bytes(d->cfg.K, hi[i] - lo[i], d->cfg.pack_mode)),
-                             iters ? iters + lo[i] : nullptr);
+                             iters ? iters + lo[i] : nullptr, pin_mode);
         if (rcs[i]) errs[i] = g_err;
     };
     std::vector<std::thread> threads;

@@ -184,3 +184,20 @@ def test_cpp_coder_over_a_device_list(built, tmp_path):
             outs.append(open(pre + ".out", "rb").read())
             assert open(pre + ".post", "rb").read() == open(str(tmp_path / ("d%s_1.post" % mode)), "rb").read()
         assert outs[0] == outs[1], mode
+
+
+def test_caller_locked_input_is_copied_directly(built):
+    """A caller that has page-locked its input itself (here: a pinned torch tensor) gets plain copies --
+    the library locks nothing -- for one device and for a device list, in several launch groups."""
+    import torch
+    g, og, K, M, z = _graph(codes.RATE_3_4_A, 1152)
+    B = 333
+    y = channel.awgn_frames(1152, 0, B, 0.5, seed=57)
+    yp = torch.from_numpy(y).pin_memory()
+    want = oracle.decode(og, y, "ms", max_iter=20)
+    for devs in (None, [0, 0]):
+        dec = L.Decoder(g, K, max_batch=64, algo="ms", max_iter=20, frames_per_lane=1, devices=devs)
+        for src in (yp.numpy(), y):
+            out, iters = dec.decode(src)
+            assert np.array_equal(out, want["out"]) and np.array_equal(iters, want["iters"]), devs
+        dec.close()
