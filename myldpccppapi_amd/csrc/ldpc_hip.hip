@@ -288,8 +288,8 @@ struct ldpc_decoder {
         DevBuf<int32_t> iters;
         uint8_t *h_out = nullptr;       /* pinned: D2H completes without blocking the host */
         int32_t *h_iters = nullptr;
-        uint8_t *h_head = nullptr;      /* two pinned pages: a group's bytes before its first page boundary and,
-                                           for the last group, after its last one */
+        uint8_t *h_head = nullptr;      /* pinned, kStageBytes: a whole small group, or a large group's bytes before
+                                           its first page boundary and (last group) after its last one */
         hipEvent_t h2d_done = nullptr, all_done = nullptr;
         bool busy = false;
         int64_t off = 0, n = 0, dst = 0, copy_bytes = 0;
@@ -1327,10 +1327,13 @@ static bool caller_locked_memory(const void *p)
     return false;
 }
 
-/* ldpc_decode on ONE device.  pin_mode 0: decide here (lock the input when the call has several
- * groups); 1: the caller runs several of these side by side on neighbouring ranges of one buffer
- * (device list) -- every group is copied from pages this call has locked itself, never as a pageable
- * source; 2: the caller's buffer is page-locked as a whole -- plain copies. */
+/* groups up to this size are copied by the CPU into a pinned staging buffer of the slot (then DMA);
+ * larger ones are DMA-read in place from pages locked for the call */
+constexpr size_t kStageBytes = (size_t)4 << 20;
+
+/* ldpc_decode on ONE device.  pin_mode 0: ask here whether the caller has page-locked the buffer;
+ * 1: it has not (a device list's parent asked once, before its threads lock anything); 2: it has --
+ * plain copies. */
 static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t *out_host,
                        int64_t out_bytes, int32_t *iters, int pin_mode)
 {
@@ -1355,7 +1358,7 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
         HIP_TRY(sl.iters.alloc((size_t)B));
         HIP_TRY(hipHostMalloc((void **)&sl.h_out, (size_t)stage_out, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc((void **)&sl.h_iters, (size_t)B * sizeof(int32_t), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void **)&sl.h_head, 4 * 4096, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&sl.h_head, kStageBytes, hipHostMallocDefault));
         HIP_TRY(hipEventCreateWithFlags(&sl.h2d_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sl.all_done, hipEventDisableTiming));
     }
@@ -1384,7 +1387,7 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
      * locked block ended in GPU memory faults twice during round 2.  A block that cannot be
      * registered (already page-locked by the caller) is copied as the runtime sees fit. */
     std::vector<void *> pinned;
-    const bool pin = pin_mode == 1 || (pin_mode == 0 && nslots > 1 && !caller_locked_memory(llr_host));
+    const bool pin = pin_mode == 1 || (pin_mode == 0 && !caller_locked_memory(llr_host));
     /* a block that cannot be locked goes through a pinned bounce buffer, chunk by chunk (slow, safe) */
     auto bounce_copy = [&](uint8_t *dst, const uint8_t *src, size_t n) -> hipError_t {
         constexpr size_t kChunk = (size_t)4 << 20;
@@ -1426,9 +1429,9 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
         const uintptr_t b1 = last ? (s1 & ~(uintptr_t)4095) : ((s1 + 4095) & ~(uintptr_t)4095);   /* end of the block */
         uint8_t *dst = reinterpret_cast<uint8_t *>(sl.llr.p);
         if (!pin) {
-            e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->copy_stream);      /* one group, nothing locked */
-        } else if (b0 >= b1) {
-            /* less than two pages in all: through the scratch */
+            e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->copy_stream);      /* locked by the caller */
+        } else if (bytes <= kStageBytes || b0 >= b1) {
+            /* small group: the CPU copies it into the slot's pinned staging buffer */
             memcpy(sl.h_head, src, bytes);
             e = hipMemcpyAsync(dst, sl.h_head, bytes, hipMemcpyHostToDevice, d->copy_stream);
         } else {
@@ -1531,7 +1534,8 @@ int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
         active += hi[i] > lo[i];
     }
     /* asked once, before any thread locks anything */
-    const int pin_mode = (n > 1 && active > 1) ? (caller_locked_memory(llr_host) ? 2 : 1) : 0;
+    (void)active;
+    const int pin_mode = caller_locked_memory(llr_host) ? 2 : 1;
     std::vector<int> rcs((size_t)n, LDPC_OK);
     std::vector<std::string> errs((size_t)n);
     auto work = [&](int i) {
