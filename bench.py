@@ -438,6 +438,10 @@ def main():
                 "bytes_per_launch": int(dom_bytes),
                 "bytes_are": "what the kernel's own loads and stores move (every Q of its rows and the fused "
                              "columns' channel values in, R of the unfused edges and the fused columns' new Q out)",
+                # the same launch priced at its share of SURVEY 8(d)'s 16 E + 4 N (round 1's `frac`; ADVICE r1 asked
+                # for the moved bytes in `frac` and this figure under its own key)
+                "algorithmic_achieved": round(dom_alg / (dom_avg_ms * 1e-3) / 1e9, 1),
+                "algorithmic_frac": round(dom_alg / (dom_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "two_kernel_formulation": {      # the same launch priced at its share of 16 E + 4 N
                     "bytes_per_launch": int(dom_alg), "achieved": round(dom_alg / (dom_avg_ms * 1e-3) / 1e9, 1),
                     "frac": round(dom_alg / (dom_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
