@@ -1550,8 +1550,15 @@ int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
         if (rcs[i]) errs[i] = g_err;
     };
     std::vector<std::thread> threads;
-    for (int i = 1; i < n; ++i) threads.emplace_back(work, i);
+    std::vector<int> inline_work;
+    for (int i = 0; i < n; ++i) d->shards[i]->have_last = false;
+    for (int i = 1; i < n; ++i) {
+        if (hi[i] <= lo[i]) continue;
+        try { threads.emplace_back(work, i); }
+        catch (...) { inline_work.push_back(i); }      /* no thread to be had: this range runs on the caller's */
+    }
     work(0);
+    for (int i : inline_work) work(i);
     for (auto &t : threads) t.join();
     for (int i = 0; i < n; ++i)
         if (rcs[i]) { g_err = errs[i]; return rcs[i]; }
