@@ -27,6 +27,19 @@ def test_library_exports_every_declared_symbol(built):
     assert lib.ldpc_abi_version() == 2
 
 
+def test_cpp_class_library_exports_the_reference_api(built):
+    """include/MyLdpc.h: every public method of the reference's `Coder` (MyLdpc.h:107-126) and the
+    free function gaussian() are defined in libmyldpc.so."""
+    so = os.path.join(ROOT, "myldpccppapi_amd", "libmyldpc.so")
+    syms = subprocess.run("nm -D --defined-only %s | c++filt" % so, shell=True, capture_output=True, text=True).stdout
+    for want in ("Coder::Coder(int, int, rate_type)", "Coder::~Coder()", "Coder::forEncoder()", "Coder::forDecoder(int)",
+                 "Coder::addDecodeType(decodeType)", "Coder::encode(char*, char*, int)",
+                 "Coder::decode(float*, char*, int, decodeType)", "Coder::test(char*, float*, int, float)",
+                 "Coder::getPriorCodeLength(int)", "Coder::getPostCodeLength(int)", "Coder::getCodeSize(int)",
+                 "gaussian(float, float)"):
+        assert want in syms, want
+
+
 def test_out_bytes_follows_tochar_and_decodecpu(built):
     assert L.out_bytes(432, 8) == 8 * 54
     # K % 8 != 0: frame b starts at (b*K)/8, each frame writes K/8 whole bytes (decodeCL.c:191-192)
