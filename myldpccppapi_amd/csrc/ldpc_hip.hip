@@ -1321,8 +1321,10 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
  * allocator)?  Then it is locked as a whole, for longer than a decode call, and is copied from directly. */
 static bool caller_locked_memory(const void *p)
 {
+    /* any memory the runtime knows (page-locked host memory; also managed or device memory handed to the
+     * host-buffer entry point by mistake or on purpose) is left to the runtime's copy engine as it is */
     hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, p) == hipSuccess) return at.type == hipMemoryTypeHost;
+    if (hipPointerGetAttributes(&at, p) == hipSuccess) return at.type != hipMemoryTypeUnregistered;
     (void)hipGetLastError();
     return false;
 }
@@ -1429,7 +1431,7 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
         const uintptr_t b1 = last ? (s1 & ~(uintptr_t)4095) : ((s1 + 4095) & ~(uintptr_t)4095);   /* end of the block */
         uint8_t *dst = reinterpret_cast<uint8_t *>(sl.llr.p);
         if (!pin) {
-            e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->copy_stream);      /* locked by the caller */
+            e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, d->copy_stream);           /* locked by the caller */
         } else if (bytes <= kStageBytes || b0 >= b1) {
             /* small group: the CPU copies it into the slot's pinned staging buffer */
             memcpy(sl.h_head, src, bytes);
