@@ -1417,6 +1417,7 @@ template <int V> __global__ void compact_finish_kernel(uint64_t *__restrict__ pa
 }
 
 /* the child's bookkeeping when it takes over `count` running frames: lanes beyond are padding */
+template <int kUnused = 0>       /* a template only so that every translation unit may include this header */
 __global__ void compact_child_state_kernel(uint64_t *__restrict__ done, int32_t *__restrict__ iters, int32_t count, int32_t max_iter)
 {
     const int j = threadIdx.x, ct = blockIdx.x, jg = ct * 64 + j;          /* 64 threads per child tile */

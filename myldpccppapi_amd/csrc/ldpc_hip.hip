@@ -32,6 +32,7 @@
 
 #include "../../include/ldpc_hip.h"
 #include "flood_kernels.hpp"
+#include "flood_tables.hpp"
 #include "layered_kernels.hpp"
 #include "fused_kernels.hpp"
 #include "ldsp_kernels.hpp"
@@ -112,91 +113,18 @@ struct ldpc_graph {
 
 namespace {
 
-using CheckFn = void (*)(const ldpc::CheckArgs);
-using VarFn = void (*)(const ldpc::VarArgs);
-
-/* c: check kernels moving 1 float per lane (narrow waves), cw: V floats per lane */
-template <int ALGO, int V, typename T, int D> struct FloodTable {
-    static void fill(CheckFn *c, CheckFn *cw, VarFn *v)
-    {
-        c[D] = ldpc::check_kernel<ALGO, D, V, 1, T>;
-        cw[D] = ldpc::check_kernel<ALGO, D, V, V, T>;
-        v[D] = ldpc::var_kernel<ALGO, D, V, T>;
-        FloodTable<ALGO, V, T, D - 1>::fill(c, cw, v);
-    }
-};
-template <int ALGO, int V, typename T> struct FloodTable<ALGO, V, T, 0> {
-    static void fill(CheckFn *c, CheckFn *cw, VarFn *v)
-    {
-        c[0] = cw[0] = ldpc::check_kernel_generic<ALGO, V, T>;
-        v[0] = ldpc::var_kernel_generic<ALGO, V, T>;
-    }
-};
-
-/* min-sum rows of degree 17..32: narrow unrolled kernels only */
-template <int V, typename T, int D> struct CheckTableMS {
-    static void fill(CheckFn *c, CheckFn *cw)
-    {
-        c[D] = cw[D] = ldpc::check_kernel<ldpc::kAlgoMS, D, V, 1, T>;
-        CheckTableMS<V, T, D - 1>::fill(c, cw);
-    }
-};
-template <int V, typename T> struct CheckTableMS<V, T, ldpc::kMaxUnrolledDegree> {
-    static void fill(CheckFn *, CheckFn *) {}
-};
-
-using LinkFn = void (*)(const ldpc::CheckArgs, const ldpc::LinkArgs);
-template <int ALGO, int V, typename T, int D> struct LinkHalf {      /* 2 values per lane: V = 4 only */
-    static LinkFn get() { return nullptr; }
-};
-template <int ALGO, typename T, int D> struct LinkHalf<ALGO, 4, T, D> {
-    static LinkFn get() { return ldpc::check_link_narrow_kernel<ALGO, D, 4, T, 2>; }
-};
-template <int ALGO, int V, typename T, int D> struct LinkTable {
-    static void fill(LinkFn *t, LinkFn *tn, LinkFn *td, LinkFn *th)
-    {
-        t[D] = ldpc::check_link_kernel<ALGO, D, V, T>;
-        tn[D] = ldpc::check_link_narrow_kernel<ALGO, D, V, T>;
-        td[D] = ldpc::check_link_narrow2_kernel<ALGO, D, V, T>;
-        th[D] = LinkHalf<ALGO, V, T, D>::get();
-        LinkTable<ALGO, V, T, D - 1>::fill(t, tn, td, th);
-    }
-};
-template <int ALGO, int V, typename T> struct LinkTable<ALGO, V, T, 1> {
-    static void fill(LinkFn *, LinkFn *, LinkFn *, LinkFn *) {}
-};
-
-/* group launches (several degree classes of a bucket in one launch, flood_kernels.hpp) */
-using CheckGroupFn = void (*)(const ldpc::CheckArgs, const ldpc::GroupClass *, int);
-using VarGroupFn = void (*)(const ldpc::VarArgs, const ldpc::GroupClass *, int);
-constexpr int kVarBuckets = 3, kCheckBuckets = 4;
-constexpr int kVarBucketLo[kVarBuckets] = {1, 5, 9}, kVarBucketHi[kVarBuckets] = {4, 8, 16};
-constexpr int kCheckBucketLo[kCheckBuckets] = {1, 9, 17, 25}, kCheckBucketHi[kCheckBuckets] = {8, 16, 24, 32};
-template <int ALGO, int V, typename T> struct GroupTable {
-    static void fill(CheckGroupFn *c, VarGroupFn *v)
-    {
-        c[0] = ldpc::check_group_kernel<ALGO, V, T, 1, 8>;
-        c[1] = ldpc::check_group_kernel<ALGO, V, T, 9, 16>;
-        c[2] = c[3] = nullptr;
-        v[0] = ldpc::var_group_kernel<ALGO, V, T, 1, 4>;
-        v[1] = ldpc::var_group_kernel<ALGO, V, T, 5, 8>;
-        v[2] = ldpc::var_group_kernel<ALGO, V, T, 9, 16>;
-    }
-};
-template <int V, typename T> struct GroupTableMSWide {     /* min-sum rows of degree 17..32 */
-    static void fill(CheckGroupFn *c)
-    {
-        c[2] = ldpc::check_group_kernel<ldpc::kAlgoMS, V, T, 17, 24>;
-        c[3] = ldpc::check_group_kernel<ldpc::kAlgoMS, V, T, 25, 32>;
-    }
-};
-
-using InitFn = void (*)(const ldpc::InitArgs);
-template <int ALGO, typename T> InitFn pick_init(int V)
-{
-    return V == 1 ? ldpc::init_kernel<ALGO, 1, T> : V == 2 ? ldpc::init_kernel<ALGO, 2, T>
-                                                         : ldpc::init_kernel<ALGO, 4, T>;
-}
+using ldpc::CheckFn;
+using ldpc::VarFn;
+using ldpc::LinkFn;
+using ldpc::CheckGroupFn;
+using ldpc::VarGroupFn;
+using ldpc::InitFn;
+using ldpc::kVarBuckets;
+using ldpc::kCheckBuckets;
+using ldpc::kVarBucketLo;
+using ldpc::kVarBucketHi;
+using ldpc::kCheckBucketLo;
+using ldpc::kCheckBucketHi;
 
 struct RowClass {
     int degree = 0;
@@ -445,7 +373,7 @@ template <int V> int compact_and_finish(ldpc_decoder *d, int64_t frames, int cou
         compact_gather_kernel<V, float><<<gn, kBlock, 0, s>>>((const float *)d->chan.p, (float *)c->chan.p, d->cmap.p, count, d->N);
     }
     compact_hard_kernel<V><<<gn, kBlock, 0, s>>>(d->hard.p, c->hard.p, d->cmap.p, count, d->N, 0);
-    compact_child_state_kernel<<<ct, 64, 0, s>>>(c->done.p, c->iters.p, count, d->cfg.max_iter);
+    compact_child_state_kernel<0><<<ct, 64, 0, s>>>(c->done.p, c->iters.p, count, d->cfg.max_iter);
     HIP_TRY(hipGetLastError());
     c->timing = false;
     c->tap_iter = 0;
@@ -807,34 +735,22 @@ int setup_flooding(ldpc_decoder *d, const ldpc_graph *g, size_t TF)
     HIP_TRY(d->R.alloc(TF * (size_t)d->E * d->msg_size));
     int rc = build_classes(d, g);
     if (rc) return rc;
-    constexpr int DM = ldpc::kMaxUnrolledDegree;
-    constexpr int DH = ldpc::kMaxUnrolledCheckDegreeMS;
-    using ldpc::hf;
-    using ldpc::kAlgoMS;
-    using ldpc::kAlgoSP;
-#define LDPC_FILL(ALGO, TYPE, VV)                                                      \
-    do {                                                                               \
-        FloodTable<ALGO, VV, TYPE, DM>::fill(d->check_fn, d->check_fn_wide, d->var_fn); \
-        LinkTable<ALGO, VV, TYPE, DM>::fill(d->link_fn, d->link_narrow_fn, d->link_deep_fn, d->link_half_fn); \
-        GroupTable<ALGO, VV, TYPE>::fill(d->check_group_fn, d->var_group_fn);          \
-        d->init_fn = pick_init<ALGO, TYPE>(VV);                                        \
-        if (ALGO == kAlgoMS) {   /* min-sum rows of degree 17..32: narrow unrolled kernels */ \
-            CheckTableMS<VV, TYPE, DH>::fill(d->check_fn, d->check_fn_wide);           \
-            GroupTableMSWide<VV, TYPE>::fill(d->check_group_fn);                       \
-            d->max_check_unrolled = DH;                                                \
-        }                                                                              \
-    } while (0)
-#define LDPC_FILL_V(ALGO, TYPE)                 \
-    do {                                        \
-        if (d->V == 1) LDPC_FILL(ALGO, TYPE, 1); \
-        else if (d->V == 2) LDPC_FILL(ALGO, TYPE, 2); \
-        else LDPC_FILL(ALGO, TYPE, 4);          \
-    } while (0)
-    if (cfg->algo == LDPC_ALGO_SP) LDPC_FILL_V(kAlgoSP, float);
-    else if (cfg->msg_dtype == LDPC_MSG_F16) LDPC_FILL_V(kAlgoMS, hf);
-    else LDPC_FILL_V(kAlgoMS, float);
-#undef LDPC_FILL_V
-#undef LDPC_FILL
+    /* the kernels live in flood_sp.hip / flood_ms.hip / flood_ms16.hip (flood_tables.hpp) */
+    ldpc::FloodFns fns;
+    if (cfg->algo == LDPC_ALGO_SP) ldpc::fill_flood_sp(d->V, &fns);
+    else if (cfg->msg_dtype == LDPC_MSG_F16) ldpc::fill_flood_ms16(d->V, &fns);
+    else ldpc::fill_flood_ms(d->V, &fns);
+    memcpy(d->check_fn, fns.check, sizeof fns.check);
+    memcpy(d->check_fn_wide, fns.check_wide, sizeof fns.check_wide);
+    memcpy(d->link_fn, fns.link, sizeof fns.link);
+    memcpy(d->link_narrow_fn, fns.link_narrow, sizeof fns.link_narrow);
+    memcpy(d->link_deep_fn, fns.link_deep, sizeof fns.link_deep);
+    memcpy(d->link_half_fn, fns.link_half, sizeof fns.link_half);
+    memcpy(d->var_fn, fns.var, sizeof fns.var);
+    memcpy(d->check_group_fn, fns.check_group, sizeof fns.check_group);
+    memcpy(d->var_group_fn, fns.var_group, sizeof fns.var_group);
+    d->init_fn = fns.init;
+    d->max_check_unrolled = fns.max_check_unrolled;
     return plan_launches(d);
 }
 

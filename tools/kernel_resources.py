@@ -1,14 +1,23 @@
 #!/usr/bin/env python3
-"""Compile csrc/ldpc_hip.hip with -Rpass-analysis=kernel-resource-usage and print one
+"""Compile the library's translation units (csrc/*.hip) with -Rpass-analysis=kernel-resource-usage and print one
 line per kernel: VGPRs, AGPRs, SGPRs, scratch, LDS, occupancy (waves/SIMD).
 Usage: tools/kernel_resources.py [regex]"""
 import os, re, subprocess, sys
 
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "myldpccppapi_amd", "csrc")
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off",
-       "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
-       "-c", "ldpc_hip.hip", "-o", "/tmp/_kr.o", "-Rpass-analysis=kernel-resource-usage"]
-out = subprocess.run(cmd, cwd=root, capture_output=True, text=True).stderr
+from concurrent.futures import ThreadPoolExecutor
+
+
+def remarks(src):
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off",
+           "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
+           "-c", src, "-o", "/tmp/_kr_%s.o" % src, "-Rpass-analysis=kernel-resource-usage"]
+    return subprocess.run(cmd, cwd=root, capture_output=True, text=True).stderr
+
+
+# the library's translation units (csrc/Makefile: HIP_OBJS)
+with ThreadPoolExecutor(4) as ex:
+    out = "\n".join(ex.map(remarks, ["ldpc_hip.hip", "flood_sp.hip", "flood_ms.hip", "flood_ms16.hip"]))
 pat = re.compile(sys.argv[1]) if len(sys.argv) > 1 else None
 cur = None
 rows = []
