@@ -854,6 +854,8 @@ struct FusedRun {
     int32_t no_pack;    /* tuning: one frame per wave also for circulants of <= 32 rows */
 };
 
+/* instantiates every kernel above: compiled by engine_fused.hip only (LDPC_ENGINE_FUSED) */
+#ifdef LDPC_ENGINE_FUSED
 inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int32_t *launched)
 {
     hipError_t e;
@@ -933,5 +935,7 @@ inline hipError_t fused_run(FusedPlan *pl, const FusedRun &r, hipStream_t s, int
     *launched = rounds;
     return hipGetLastError();
 }
+
+#endif  /* LDPC_ENGINE_FUSED */
 
 }  // namespace ldpc

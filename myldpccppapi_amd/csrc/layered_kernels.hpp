@@ -279,6 +279,8 @@ __global__ __launch_bounds__(kBlock) void layered_init_kernel(const LayeredInitA
 
 /* ------------------------------------------------------------- host side */
 
+constexpr int kMaxUnrolledLayerDegree = 24;
+
 struct LayerGroup {
     int layer = 0, degree = 0, count = 0;
     int32_t *e0 = nullptr; /* device */
@@ -354,6 +356,9 @@ struct LayeredRun {
     int32_t *summary;
 };
 
+/* The launching code instantiates every kernel above: only the translation unit that defines
+ * LDPC_ENGINE_LAYERED (engine_layered.hip) compiles it; the host driver calls engine_layered_run. */
+#ifdef LDPC_ENGINE_LAYERED
 using LayerFn = void (*)(const LayerArgs);
 template <int V, int D, bool HOST = false> struct LayerTable {
     static void fill(LayerFn *t) { t[D] = layer_kernel<D, V, HOST>; LayerTable<V, D - 1, HOST>::fill(t); }
@@ -362,7 +367,6 @@ template <int V, bool HOST> struct LayerTable<V, 0, HOST> {
     static void fill(LayerFn *t) { t[0] = HOST ? nullptr : layer_kernel_generic<V>; }
 };
 
-constexpr int kMaxUnrolledLayerDegree = 24;
 
 template <int V> __global__ void layered_summary_kernel(const int32_t *iters, const uint64_t *done,
                                                         int64_t frames, int32_t *summary)
@@ -445,6 +449,8 @@ inline hipError_t layered_run(LayeredPlan *pl, const LayeredRun &r, hipStream_t 
     if (pl->V == 2) return layered_run_v<2>(pl, r, s, launched);
     return layered_run_v<4>(pl, r, s, launched);
 }
+
+#endif  /* LDPC_ENGINE_LAYERED */
 
 /* which: 0 = R [frame][E], 2 = P [frame][N], 3 = bits [frame][N] */
 inline hipError_t layered_dump(LayeredPlan *pl, int which, float *host_out, int64_t count, int64_t frames,

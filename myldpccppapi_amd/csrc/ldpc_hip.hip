@@ -36,6 +36,7 @@
 #include "layered_kernels.hpp"
 #include "fused_kernels.hpp"
 #include "ldsp_kernels.hpp"
+#include "engines.hpp"
 #include "channel_kernels.hpp"
 #include "tune.hpp"
 
@@ -1002,7 +1003,7 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
         /* flood_ldsp_kernel<.., CHAIN = false> (posteriors in LDS, 16-byte check records) wherever it fits
          * with two workgroups per CU, else / with LDPC_TUNE_OFF(LDPC_TUNE_LDSP) the LDS-resident fused_flood_kernel */
         if (!ldpc::tune_forced_off(tune.ldsp)) {
-            HIP_TRY(ldpc::ldsp_plan_create(&d->ldsp, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows, cfg->K,
+            HIP_TRY(ldpc::engine_ldsp_plan_create(&d->ldsp, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows, cfg->K,
                                            cfg->max_batch, cfg->device, tune, /*flood=*/2));
             if (d->ldsp.eligible && (ldpc::tune_forced_on(tune.ldsp) || d->ldsp.lds_bytes <= 80 * 1024)) d->use_ldsp = true;
             else ldpc::ldsp_plan_destroy(&d->ldsp);
@@ -1032,8 +1033,8 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
              * edge updates/s; circulants of <= 32 rows run several frames per wave in both).
              * LDPC_TUNE_OFF(LDPC_TUNE_LDSP) forbids it (the LDS-resident kernel is then used where it applies). */
             if (!ldpc::tune_forced_off(tune.ldsp)) {
-                HIP_TRY(ldpc::ldsp_plan_create(&d->ldsp, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows,
-                                               cfg->K, cfg->max_batch, cfg->device, tune));
+                HIP_TRY(ldpc::engine_ldsp_plan_create(&d->ldsp, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows,
+                                               cfg->K, cfg->max_batch, cfg->device, tune, /*flood=*/0));
                 if (d->ldsp.eligible) d->use_fused = d->use_ldsp = true;
             }
         }
@@ -1065,7 +1066,7 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
              * at 16 384 frames, 2.6 / 0.9 / 1.3 at full work), 2.4 / 2.0 / 1.7 / 1.2x the streaming kernels on
              * BG1-profile codes at Z = 64 / 128 / 256 / 384.  LDPC_TUNE_ON / OFF(LDPC_TUNE_LDSP) forces / forbids it. */
             if (cfg->algo == LDPC_ALGO_MS && !ldpc::tune_forced_off(tune.fused) && !ldpc::tune_forced_off(tune.ldsp)) {
-                HIP_TRY(ldpc::ldsp_plan_create(&d->ldsp, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows,
+                HIP_TRY(ldpc::engine_ldsp_plan_create(&d->ldsp, g->M, g->N, g->E, g->row_ptr, g->cols, cfg->layer_rows,
                                                cfg->K, cfg->max_batch, cfg->device, tune, /*flood=*/1));
                 if (d->ldsp.eligible && (ldpc::tune_forced_on(tune.ldsp) || d->ldsp.lds_bytes <= 80 * 1024))
                     d->use_fused = d->use_ldsp = true;
@@ -1204,8 +1205,8 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
                            ldpc::tune_pick(d->tune.fused_pack, true) ? 0 : 1};
         hipError_t e = span_begin(d, s, 2, 0, (int64_t)frames * (4 * d->N + d->cfg.K / 8));
         if (e == hipSuccess)
-            e = d->use_ldsp ? ldpc::ldsp_run(&d->ldsp, run, s, &d->last_iterations)
-                            : ldpc::fused_run(&d->fused, run, s, &d->last_iterations);
+            e = d->use_ldsp ? ldpc::engine_ldsp_run(&d->ldsp, run, s, &d->last_iterations)
+                            : ldpc::engine_fused_run(&d->fused, run, s, &d->last_iterations);
         if (e == hipSuccess) e = span_end(d, s);
         rc = (e == hipSuccess) ? LDPC_OK : fail(LDPC_ERR_HIP, "fused decode: %s", hipGetErrorString(e));
     } else if (d->cfg.algo == LDPC_ALGO_LAYERED || d->cfg.algo == LDPC_ALGO_LAYERED_HOST) {
@@ -1221,7 +1222,7 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
         run.early_term = d->cfg.early_term; run.pack_mode = d->cfg.pack_mode;
         run.hard = d->hard.p; run.failw = d->failw.p; run.done = d->done.p; run.iters = d->iters.p;
         run.row_ptr = d->row_ptr.p; run.edge_col = d->edge_col.p; run.summary = d->summary.p;
-        hipError_t e = ldpc::layered_run(&d->layered, run, s, &d->last_iterations);
+        hipError_t e = ldpc::engine_layered_run(&d->layered, run, s, &d->last_iterations);
         rc = (e == hipSuccess) ? LDPC_OK
                                : fail(LDPC_ERR_HIP, "layered decode: %s", hipGetErrorString(e));
     } else if (d->V == 1) rc = run_flooding<1>(d, llr_dev, frames, out_dev, std::min(out_bytes, need), iters_dev, s);

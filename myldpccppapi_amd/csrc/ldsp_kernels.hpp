@@ -401,6 +401,7 @@ void layered_ldsp_kernel(const LdspArgs a)
  * wave -- lanes [g z, (g + 1) z) are the rows of frame g -- each with its own posteriors in LDS and
  * its own record ring.  One wave per workgroup, so "barriers" only order the wave's own LDS
  * traffic; a frame whose syndrome is clean goes idle until the wave's last frame is done. */
+template <int kUnused = 0>       /* a template only so that several translation units may include this header */
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LDPC_LDSP_WAVES_PER_EU)))
 void layered_ldsp_packed_kernel(const LdspArgs a, const int G)
 {
@@ -1040,6 +1041,9 @@ inline void ldsp_plan_destroy(LdspPlan *pl)
     *pl = LdspPlan();
 }
 
+/* the plan builder and the launcher reference every kernel above: compiled by engine_ldsp.hip only
+ * (LDPC_ENGINE_LDSP); the host driver calls engine_ldsp_plan_create / engine_ldsp_run */
+#ifdef LDPC_ENGINE_LDSP
 typedef void (*LdspKernel)(const LdspArgs);
 inline LdspKernel ldsp_kernel_for(int maxw) { return maxw <= 8 ? layered_ldsp_kernel<8> : layered_ldsp_kernel<16>; }
 
@@ -1113,7 +1117,7 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
         return e;
     const void *k = flood ? (pl->wg_frames > 1 ? (flood == 1 ? (const void *)flood_ldsp_packed_kernel<true> : (const void *)flood_ldsp_packed_kernel<false>)
                                                : (const void *)flood_ldsp_kernel_for(mw <= 8 ? 8 : 16, flood))
-                    : pl->wg_frames > 1 ? (const void *)layered_ldsp_packed_kernel : (const void *)ldsp_kernel_for(mw <= 8 ? 8 : 16);
+                    : pl->wg_frames > 1 ? (const void *)layered_ldsp_packed_kernel<0> : (const void *)ldsp_kernel_for(mw <= 8 ? 8 : 16);
     /* the attribute belongs to the function, not to this plan: always the maximum, so that decoders
      * of different codes can coexist */
     if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdspMaxLds))) return e;
@@ -1154,10 +1158,12 @@ inline hipError_t ldsp_run(LdspPlan *pl, const FusedRun &r, hipStream_t s, int32
     if (pl->flood == 1 && pl->wg_frames > 1) flood_ldsp_packed_kernel<true><<<grid, 64, pl->lds_bytes, s>>>(a, pl->wg_frames);
     else if (pl->flood && pl->wg_frames > 1) flood_ldsp_packed_kernel<false><<<grid, 64, pl->lds_bytes, s>>>(a, pl->wg_frames);
     else if (pl->flood) flood_ldsp_kernel_for(pl->maxw, pl->flood)<<<grid, pl->block, pl->lds_bytes, s>>>(a);
-    else if (pl->wg_frames > 1) layered_ldsp_packed_kernel<<<grid, 64, pl->lds_bytes, s>>>(a, pl->wg_frames);
+    else if (pl->wg_frames > 1) layered_ldsp_packed_kernel<0><<<grid, 64, pl->lds_bytes, s>>>(a, pl->wg_frames);
     else ldsp_kernel_for(pl->maxw)<<<grid, pl->block, pl->lds_bytes, s>>>(a);
     *launched = rounds;
     return hipGetLastError();
 }
+
+#endif  /* LDPC_ENGINE_LDSP */
 
 }  // namespace ldpc

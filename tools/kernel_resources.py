@@ -16,8 +16,8 @@ def remarks(src):
 
 
 # the library's translation units (csrc/Makefile: HIP_OBJS)
-with ThreadPoolExecutor(4) as ex:
-    out = "\n".join(ex.map(remarks, ["ldpc_hip.hip", "flood_sp.hip", "flood_ms.hip", "flood_ms16.hip"]))
+with ThreadPoolExecutor(7) as ex:
+    out = "\n".join(ex.map(remarks, ["ldpc_hip.hip", "flood_sp.hip", "flood_ms.hip", "flood_ms16.hip", "engine_ldsp.hip", "engine_fused.hip", "engine_layered.hip"]))
 pat = re.compile(sys.argv[1]) if len(sys.argv) > 1 else None
 cur = None
 rows = []
