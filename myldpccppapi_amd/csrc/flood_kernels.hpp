@@ -1047,8 +1047,14 @@ __device__ __forceinline__ void var_columns(const T *Rt, T *Qt, const T *chan_t,
     }
 }
 
+/* build-time experiment hook: -DLDPC_VAR_WAVES=n asks the compiler for n waves per SIMD */
+#ifdef LDPC_VAR_WAVES
+#define LDPC_VAR_ATTR __attribute__((amdgpu_waves_per_eu(LDPC_VAR_WAVES, LDPC_VAR_WAVES)))
+#else
+#define LDPC_VAR_ATTR
+#endif
 template <int ALGO, int D, int V, typename T>
-__global__ __launch_bounds__(kBlock) void var_kernel(const VarArgs a)
+__global__ __launch_bounds__(kBlock) LDPC_VAR_ATTR void var_kernel(const VarArgs a)
 {
     constexpr size_t F = 64 * V;
     const int lane = threadIdx.x & 63;
