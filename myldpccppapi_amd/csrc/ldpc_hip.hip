@@ -1291,10 +1291,12 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
         return LDPC_OK;
     };
     /* A copy from pageable memory waits for the device's other work (measured: 151 ms behind a
-     * 140 ms decode instead of 19 ms), so a call of several groups page-locks the caller's input for
-     * its duration: a true DMA that runs beside the previous group's kernels.  The rule that keeps
-     * this safe: the GPU only ever reads (a) this library's own pinned scratch and (b) WHOLE pages
-     * that this call has registered itself and that lie strictly inside its own byte range.
+     * 140 ms decode instead of 19 ms), so the input never travels as a pageable source: a group of
+     * up to kStageBytes is copied by the CPU into the slot's pinned staging buffer, a larger one is
+     * page-locked where it lies for the duration of the call -- a true DMA that runs beside the
+     * previous group's kernels.  The rule that keeps this safe: the GPU only ever reads (a) this
+     * library's own pinned buffers and (b) WHOLE pages that this call has registered itself and that
+     * lie strictly inside its own byte range.
      * Group k owns the block from its first page boundary up to the next group's first page boundary
      * (the last group: up to its last page boundary); blocks are page-disjoint, each is registered
      * just before its copy -- i.e. while the previous group decodes -- and all are released only
