@@ -13,7 +13,14 @@
  *   var_i      : bits_i = hard(R_i) (frozen frames keep theirs); Q_i = var(R_i)
  *   syndrome_i : fail_i = any parity check of bits_i odd          } early_term only
  *   state_i    : frames with clean bits_i freeze, iters = i        } (and after the last round)
+ *   tail_i     : (asynchronous callers) hand the last running frames over to the overflow tiles
  * then pack.
+ *
+ * Also here: decoders over several devices (ldpc_decoder_create_multi: one host thread per device
+ * range), the host-buffer path and its staging rule (decode_host), the creation-time choice of the
+ * column-fused check kernel's form (calibrate_link) and the launch plan (plan_launches).  The
+ * kernels themselves are instantiated in other translation units: flood_sp / flood_ms / flood_ms16
+ * (flood_tables.hpp) and engine_ldsp / engine_fused / engine_layered (engines.hpp).
  */
 #include <hip/hip_runtime.h>
 
