@@ -123,7 +123,7 @@ enum ldpc_tune_field {
     LDPC_TUNE_LDSP_PACK = 6,    /* several frames per wave for circulants of <= 32 rows             */
     LDPC_TUNE_LINK_NARROW = 8,  /* column-fused check kernel in narrow waves (1 value per lane) or wide
                                    (V per lane); default: both -- and LINK_HALF -- are timed when a
-                                   decoder of >= 4 tiles is created and the fastest is kept          */
+                                   decoder with 2 or 4 frames per lane is created and the fastest is kept          */
     LDPC_TUNE_CHECK_WIDE = 10,  /* check kernels move V floats per lane (default off)               */
     LDPC_TUNE_SYN_XCD = 12,     /* XCD-aware syndrome grid (default on)                             */
     LDPC_TUNE_FUSED_PACK = 14,  /* fused layered kernel: several frames per wave (default on)       */

@@ -766,8 +766,9 @@ int setup_flooding(ldpc_decoder *d, const ldpc_graph *g, size_t TF)
  * waves (1 value per lane, 48 VGPRs).  Which one is faster is a property of the box and its power
  * state, not of the code: round 1 found narrow ahead by 2 % on its slow boxes, round 2's boxes run
  * wide 10-17 % faster (profiles/r02_ab_link_wide.txt).  Unless the caller fixes the choice
- * (LDPC_TUNE_LINK_NARROW), a decoder with several tiles therefore times both on its own arrays when
- * it is created -- interleaved launches, a few milliseconds -- and keeps the faster.  The arrays hold
+ * (LDPC_TUNE_LINK_NARROW), a decoder with more than one frame per lane therefore times the forms on its
+ * own arrays when it is created -- interleaved launches, a few milliseconds -- and keeps the fastest
+ * (wide also wins at 256 ... 1024 frames: +4 ... +8 % on the whole decode).  The arrays hold
  * zeros, which the first decode overwrites; results do not depend on the choice (the tests run both). */
 template <int V> int calibrate_link(ldpc_decoder *d)
 {
@@ -1085,7 +1086,7 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
             int rc = setup_flooding(d, g, TF);
             if (rc) return rc;
             /* narrow or wide column-fused check kernel: measured here unless the caller says which */
-            if (tune.link_narrow == 0 && tune.link_half == 0 && !tune.link_deep && d->T >= 4 && !t_creating_child) {
+            if (tune.link_narrow == 0 && tune.link_half == 0 && !tune.link_deep && d->V >= 2 && !t_creating_child) {
                 rc = d->V == 1 ? calibrate_link<1>(d) : d->V == 2 ? calibrate_link<2>(d) : calibrate_link<4>(d);
                 if (rc) return rc;
             }
