@@ -27,6 +27,18 @@ def test_library_exports_every_declared_symbol(built):
     assert lib.ldpc_abi_version() == 2
 
 
+def test_c_abi_header_compiles_and_links_as_plain_c(built, tmp_path):
+    """include/ldpc_hip.h is a C header: a C99 program includes it, links libldpc_hip.so and uses the
+    host-only entry points (graph, config defaults, shard arithmetic, error text)."""
+    exe = str(tmp_path / "cabi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "cabi_smoke.c"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "myldpccppapi_amd"), "-lldpc_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "myldpccppapi_amd")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "cabi ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
+
+
 def test_cpp_class_library_exports_the_reference_api(built):
     """include/MyLdpc.h: every public method of the reference's `Coder` (MyLdpc.h:107-126) and the
     free function gaussian() are defined in libmyldpc.so."""
