@@ -1581,9 +1581,11 @@ int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t ca
         const int phase = (sp.kind == 4 || sp.kind == 5) ? 0 : (sp.kind == 6 ? 1 : sp.kind);   /* check / variable node */
         char name[64];
         if (sp.kind == 3) snprintf(name, sizeof name, "other");
-        else if (d->use_fused)      /* whole decode in one launch; bytes = channel values in + packed bits out */
-            snprintf(name, sizeof name, "%s", d->use_ldsp ? (d->cfg.algo == LDPC_ALGO_LAYERED ? "layered_ldsp_kernel" : "flood_ldsp_kernel")
-                     : d->cfg.algo == LDPC_ALGO_SP ? "fused_sp_kernel"
+        else if (d->use_fused && d->use_ldsp)   /* whole decode in one launch; [persistent grid x workgroup size, frames per workgroup] */
+            snprintf(name, sizeof name, "%s[%dx%d,%d]", d->cfg.algo == LDPC_ALGO_LAYERED ? "layered_ldsp_kernel" : "flood_ldsp_kernel",
+                     d->ldsp.grid, d->ldsp.block, d->ldsp.wg_frames);
+        else if (d->use_fused)      /* bytes = channel values in + packed bits out */
+            snprintf(name, sizeof name, "%s", d->cfg.algo == LDPC_ALGO_SP ? "fused_sp_kernel"
                      : d->cfg.algo == LDPC_ALGO_LAYERED ? "fused_layered_kernel" : "fused_flood_kernel");
         else if (sp.kind == 5 || sp.kind == 6)
             snprintf(name, sizeof name, "%s<%s,%d-%d,%d>", sp.kind == 5 ? "check_group_kernel" : "var_group_kernel",

@@ -245,10 +245,9 @@ void layered_ldsp_kernel(const LdspArgs a)
 {
     extern __shared__ float lds[];
     float *P = lds;                                                             /* [lds_cols][z] */
-    const int r = (int)threadIdx.x, LANES = (int)blockDim.x, MW = LANES >> 6, wave = r >> 6;
+    const int r = (int)threadIdx.x, LANES = (int)blockDim.x;
     const int z = a.z;
-    uint64_t *extneg = reinterpret_cast<uint64_t *>(lds + (((size_t)a.lds_cols * z + 1) & ~(size_t)1));  /* [layers][MW] */
-    uint32_t *wg_flag = reinterpret_cast<uint32_t *>(extneg + (size_t)a.layers * MW);
+    uint32_t *wg_flag = reinterpret_cast<uint32_t *>(lds + (((size_t)a.lds_cols * z + 1) & ~(size_t)1));
     const bool row = r < z;
     const size_t ring = (size_t)blockIdx.x * ((size_t)a.layers * z) + r;        /* [layer][z], mine: + r */
     uint4 *recs = a.recs + ring;
@@ -291,12 +290,14 @@ void layered_ldsp_kernel(const LdspArgs a)
                 /* the next layer step's record (wrapping into the next iteration), requested before
                  * this step's work; with a single layer it is this step's own output */
                 const int ln = l + 1 < a.layers ? l + 1 : 0;
-                uint4 nxt = uint4{0u, 0u, 0u, 0u};
-                if (row && a.layers > 1) nxt = recs[(size_t)ln * z];
+                /* by every lane, outside any branch: a conditional request makes the compiler copy the
+                 * registers, and wait for them, where the branch ends -- at once.  Lanes beyond the last row
+                 * read their neighbours' records (the rings end with 64 spare ones). */
+                uint4 nxt = recs[(size_t)ln * z];
                 const int dl = hdr[l * 4], ext = hdr[l * 4 + 1];
                 const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
+                uint4 rec = uint4{0u, 0u, 0u, 0u};
                 if (row) {
-                    uint4 rec;
                     uint32_t par = 0;                               /* parity of the row's hard decisions as it leaves them */
                     bool done = false;
                     if (ext) {
@@ -316,17 +317,13 @@ void layered_ldsp_kernel(const LdspArgs a)
                     }
                     if (!done) rec = ldsp_row_any(P, pk, dl, ext, z, r, cur, zfs + (size_t)l * z, &par);
                     last_bad = par;
-                    /* the requested record has had this step's work to arrive: take it BEFORE the
-                     * store below is issued, or the wait for it would cover the store as well and
-                     * put a full memory round trip into every layer step */
-                    asm volatile("" : "+v"(nxt.x), "+v"(nxt.y), "+v"(nxt.z), "+v"(nxt.w) : : "memory");
-                    recs[(size_t)l * z] = rec;
-                    if (a.layers == 1) nxt = rec;
-                    if (ext) {                                      /* hard decision of the external column */
-                        const uint64_t neg = __ballot(__uint_as_float(rec.w) < 0.0f);
-                        if ((r & 63) == 0) extneg[l * MW + wave] = neg;
-                    }
                 }
+                /* the requested record has had this step's work to arrive: take it -- on every path, not
+                 * inside the branch above -- BEFORE the store below is issued, or the wait for it would
+                 * cover the store as well and put a full memory round trip into every layer step */
+                asm volatile("" : "+v"(nxt.x), "+v"(nxt.y), "+v"(nxt.z), "+v"(nxt.w) : : "memory");
+                if (row) recs[(size_t)l * z] = rec;
+                if (a.layers == 1) nxt = rec;
                 lds_barrier();
                 cur = nxt;
             }
@@ -350,7 +347,8 @@ void layered_ldsp_kernel(const LdspArgs a)
 #undef LDPC_LDSP_CASE
                         default: break;
                         }
-                        if (ext) par ^= extneg[l * MW + wave];
+                        /* hard decision of the layer's external column: its posterior is in my record */
+                        if (ext) par ^= __ballot(__uint_as_float(recs[(size_t)l * z].w) < 0.0f);
                         bad |= par;
                     }
                 }
@@ -1099,7 +1097,10 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
     if (mw == 1 && will_pack) frames_per_wg = 64 / z;
     const size_t frame_bytes = ((((size_t)lds_cols * z + 1) & ~(size_t)1)) * sizeof(float) * (flood ? 2 : 1);   /* flooding: old and new image */
     while (frames_per_wg > 1 && frames_per_wg * frame_bytes + (size_t)layers * sizeof(uint64_t) + 8 > 60 * 1024) --frames_per_wg;
-    const size_t lds_bytes = frames_per_wg * frame_bytes + (size_t)layers * mw * sizeof(uint64_t) + 8;
+    /* behind the posteriors: a flag word, and (all kernels but layered_ldsp_kernel, which reads them from its
+     * records) the lane masks of the external columns' hard decisions */
+    const bool masks = flood || frames_per_wg > 1;
+    const size_t lds_bytes = frames_per_wg * frame_bytes + (masks ? (size_t)layers * mw * sizeof(uint64_t) : 0) + 8;
     if (lds_bytes > kLdspMaxLds || lds_cols >= 32768) return hipSuccess;
     pl->wg_frames = frames_per_wg;
     pl->flood = flood;
@@ -1125,12 +1126,20 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, pl->block, lds_bytes))) return e;
     if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device))) return e;
     if (per_cu < 1 || cus < 1) return hipErrorInvalidValue;
-    if (tune.ldsp_per_cu) per_cu = std::max(1, std::min(per_cu, tune.ldsp_per_cu));
+    /* The record rings of all resident workgroups are re-read once per iteration: they must stay in the
+     * Infinity Cache (256 MiB less what streams through between two uses).  BG1 at Z = 384: 276 KiB per frame;
+     * 3 workgroups per CU = 207 MiB: 23.5 ms per batch; 4 per CU (LDS and registers allow it) = 276 MiB: 27.7 ms
+     * (profiles/r02_ab_ldsp_resident.txt). */
+    const size_t ring_bytes = (size_t)frames_per_wg * M * sizeof(uint4);
+    const int cache_cap = (int)std::max<size_t>(1, ((size_t)224 << 20) / ((size_t)cus * ring_bytes));
+    if (tune.ldsp_per_cu) per_cu = std::max(1, tune.ldsp_per_cu);   /* a forced value ignores both rules: the grid is persistent */
+    else per_cu = std::min(per_cu, cache_cap);
     pl->per_cu = per_cu;
     pl->grid = (int32_t)std::min<int64_t>((std::max<int64_t>(max_batch, 1) + pl->wg_frames - 1) / pl->wg_frames, (int64_t)per_cu * cus);
     if (tune.ldsp_grid) pl->grid = std::max(1, std::min(pl->grid, tune.ldsp_grid));
-    if ((e = hipMalloc((void **)&pl->recs, (size_t)pl->grid * pl->wg_frames * M * sizeof(uint4)))) return e;
-    if ((e = hipMalloc((void **)&pl->zf, (size_t)pl->grid * pl->wg_frames * M * sizeof(uint32_t)))) return e;
+    /* + 64: lanes beyond the last row request records too (never used) */
+    if ((e = hipMalloc((void **)&pl->recs, ((size_t)pl->grid * pl->wg_frames * M + 64) * sizeof(uint4)))) return e;
+    if ((e = hipMalloc((void **)&pl->zf, ((size_t)pl->grid * pl->wg_frames * M + 64) * sizeof(uint32_t)))) return e;
     pl->eligible = true;
     return hipSuccess;
 }
