@@ -37,6 +37,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "fused_kernels.hpp"
@@ -44,6 +45,7 @@
 namespace ldpc {
 
 constexpr int kLdspMaxDeg = 24;
+constexpr int kLdspPackStride = 4 * kLdspMaxDeg;   /* LdspArgs::pack, ints per layer */
 constexpr uint32_t kLdspIrregular = 1u << 29;
 constexpr size_t kLdspMaxLds = 160 * 1024 - 512;     /* one workgroup's dynamic LDS */
 
@@ -57,8 +59,9 @@ struct LdspArgs {
     uint4 *__restrict__ recs;             /* [grid][layers*z] check records */
     uint32_t *__restrict__ zf;            /* [grid][layers*z] "message is a zero" bits of irregular records */
     const int32_t *__restrict__ hdr;      /* [layers][4]: LDS entries, has external column, its first index, its shift */
-    const int32_t *__restrict__ pack;     /* [layers][2][24]: byte offset of the entry's LDS column (slot*z*4), then
-                                             4 * its shift: ready-made operands, no scalar arithmetic per edge */
+    const int32_t *__restrict__ pack;     /* [layers][4][24]: byte offset of the entry's LDS column (slot*z*4); 4 * its
+                                             shift; their sum; 4 * (z - shift): ready-made operands, no scalar
+                                             arithmetic per edge (ldsp_at uses the first two rows, ldsp_at_abs the others) */
     const int32_t *__restrict__ col_slot; /* [N/z]: LDS slot of the block column, -1 = travels with a record */
     const int32_t *__restrict__ layer_e0; /* [layers]: edge id of the layer's first edge */
     int64_t frames, out_bytes;
@@ -99,6 +102,18 @@ __device__ __forceinline__ float *ldsp_at(float *P, int column_bytes, int shift4
     const uint32_t t = (uint32_t)r4 + (uint32_t)shift4;
     const uint32_t tw = t - (uint32_t)z4;                           /* wraps to a huge value when t < z4 */
     return reinterpret_cast<float *>(reinterpret_cast<char *>(P) + ((t < tw ? t : tw) + (uint32_t)column_bytes));
+}
+
+/* The same address when the posteriors start at LDS address 0 (a kernel without static LDS), from the table's
+ * other two rows: r4 + (column_bytes + shift4), less z4 for the rows that wrap (r4 >= z4 - shift4) --
+ * compare, select, three-operand add; an LDS pointer made from the number, no base to add */
+typedef __attribute__((address_space(3))) float ldpc_lds_float;
+__device__ __forceinline__ ldpc_lds_float *ldsp_at_abs(int colshift, int thresh, int r4, int negz4)
+{
+    const uint32_t wrap = (uint32_t)r4 >= (uint32_t)thresh ? (uint32_t)negz4 : 0u;
+    uint32_t at;                    /* the compiler makes two adds of this sum */
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(at) : "v"(r4), "s"(colshift), "v"(wrap));
+    return reinterpret_cast<ldpc_lds_float *>((uintptr_t)at);
 }
 
 /* Message k of a d-entry record: cl_sign(q) is +-1 for a regular q, so R = +-sel; it is +-0 for
@@ -164,8 +179,10 @@ __device__ __forceinline__ uint4 ldsp_row_any(float *P, ldpc_const_i32 pk, int d
 }
 
 /* Exact row width (DL entries in LDS + EXT external), straight-line code.  Returns false,
- * wave-uniformly and with P untouched, when some row of the wave needs ldsp_row_any. */
-template <int DL, int EXT>
+ * wave-uniformly and with P untouched, when some row of the wave needs ldsp_row_any.  ABS: the
+ * posteriors start at LDS address 0 (ldsp_at_abs).  PAR = false: *par is left alone (the caller takes
+ * the parity of the one layer it needs from the posteriors, ldsp_row_parity). */
+template <int DL, int EXT, bool ABS = false, bool PAR = true>
 __device__ __forceinline__ bool ldsp_row(float *P, ldpc_const_i32 pk, int z, int r, const uint4 old, uint4 *out,
                                          uint32_t *par)
 {
@@ -173,9 +190,13 @@ __device__ __forceinline__ bool ldsp_row(float *P, ldpc_const_i32 pk, int z, int
     constexpr int DLA = DL > 0 ? DL : 1;
     if (__ballot((old.z & kLdspIrregular) != 0u) != 0ull) return false;
     float q[D];
-    float *at[DLA];
+    typedef typename std::conditional<ABS, ldpc_lds_float, float>::type cell;     /* ABS: P is LDS address 0 */
+    cell *at[DLA];
 #pragma unroll
-    for (int k = 0; k < DL; ++k) at[k] = ldsp_at(P, pk[k], pk[kLdspMaxDeg + k], r * 4, z * 4);
+    for (int k = 0; k < DL; ++k) {
+        if constexpr (ABS) at[k] = ldsp_at_abs(pk[2 * kLdspMaxDeg + k], pk[3 * kLdspMaxDeg + k], r * 4, -(z * 4));
+        else at[k] = ldsp_at(P, pk[k], pk[kLdspMaxDeg + k], r * 4, z * 4);
+    }
     const int obind = (int)((old.z >> 24) & 31u);
 #pragma unroll
     for (int k = 0; k < D; ++k) {
@@ -207,7 +228,7 @@ __device__ __forceinline__ bool ldsp_row(float *P, ldpc_const_i32 pk, int z, int
         if (k < DL) *at[k < DL ? k : 0] = pn;
         else pext = __float_as_uint(pn);
         signs = __builtin_amdgcn_alignbit(signs, rn, 31);           /* (signs << 1) | sign(rn) */
-        px ^= __float_as_uint(pn);                                  /* regular q, sel > 0: pn < 0 <=> sign bit */
+        if (PAR) px ^= __float_as_uint(pn);                         /* regular q, sel > 0: pn < 0 <=> sign bit */
     }
     *out = uint4{mb, mc, signs | ((uint32_t)bind << 24), pext};
     *par = px >> 31;
@@ -284,8 +305,22 @@ void layered_ldsp_kernel(const LdspArgs a)
         __syncthreads();
         int time = 0;
         bool clean = false;
+        /* lane mask of the wave's rows of layer l whose hard decisions have odd parity */
+        auto layer_odd = [&](const int l) {
+            const int dl = hdr[l * 4], ext = hdr[l * 4 + 1];
+            const ldpc_const_i32 pk = pack + (size_t)l * kLdspPackStride;
+            uint64_t par = 0;
+            switch (dl) {
+#define LDPC_LDSP_CASE(D) case D + 1: par = ldsp_row_parity<D + 1>(P, pk, z, r); break;
+                LDPC_LDSP_WIDTHS(LDPC_LDSP_CASE)
+#undef LDPC_LDSP_CASE
+            default: break;
+            }
+            /* hard decision of the layer's external column: its posterior is in my record */
+            if (ext) par ^= __ballot(__uint_as_float(recs[(size_t)l * z].w) < 0.0f);
+            return par;
+        };
         while (true) {
-            uint32_t last_bad = 0;
             for (int l = 0; l < a.layers; ++l) {
                 /* the next layer step's record (wrapping into the next iteration), requested before
                  * this step's work; with a single layer it is this step's own output */
@@ -295,28 +330,27 @@ void layered_ldsp_kernel(const LdspArgs a)
                  * read their neighbours' records (the rings end with 64 spare ones). */
                 uint4 nxt = recs[(size_t)ln * z];
                 const int dl = hdr[l * 4], ext = hdr[l * 4 + 1];
-                const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
+                const ldpc_const_i32 pk = pack + (size_t)l * kLdspPackStride;
                 uint4 rec = uint4{0u, 0u, 0u, 0u};
                 if (row) {
-                    uint32_t par = 0;                               /* parity of the row's hard decisions as it leaves them */
+                    uint32_t par = 0;                               /* (ldsp_row_any's; not used here) */
                     bool done = false;
                     if (ext) {
                         switch (dl) {
-#define LDPC_LDSP_CASE(D) case D: done = ldsp_row<D, 1>(P, pk, z, r, cur, &rec, &par); break;
+#define LDPC_LDSP_CASE(D) case D: done = ldsp_row<D, 1, true, false>(P, pk, z, r, cur, &rec, &par); break;
                             LDPC_LDSP_WIDTHS(LDPC_LDSP_CASE)
 #undef LDPC_LDSP_CASE
                         default: break;
                         }
                     } else {
                         switch (dl) {
-#define LDPC_LDSP_CASE(D) case D + 1: done = ldsp_row<D + 1, 0>(P, pk, z, r, cur, &rec, &par); break;
+#define LDPC_LDSP_CASE(D) case D + 1: done = ldsp_row<D + 1, 0, true, false>(P, pk, z, r, cur, &rec, &par); break;
                             LDPC_LDSP_WIDTHS(LDPC_LDSP_CASE)
 #undef LDPC_LDSP_CASE
                         default: break;
                         }
                     }
                     if (!done) rec = ldsp_row_any(P, pk, dl, ext, z, r, cur, zfs + (size_t)l * z, &par);
-                    last_bad = par;
                 }
                 /* the requested record has had this step's work to arrive: take it -- on every path, not
                  * inside the branch above -- BEFORE the store below is issued, or the wait for it would
@@ -331,28 +365,17 @@ void layered_ldsp_kernel(const LdspArgs a)
              * after the last one (its only use then is the frame's converged flag) */
             ++time;
             int any_bad = 1;
-            /* the rows of the last layer leave their columns in the iteration's final state, so
-             * their parities are known already: only when all of them are even (hardly ever
-             * before the frame has converged) the other layers need to be looked at */
-            if ((a.early_term || time == a.rounds) && !wg_any(row && last_bad)) {
-                uint64_t bad = 0;
-                if (row) {
-                    for (int l = 0; l < a.layers; ++l) {
-                        const int dl = hdr[l * 4], ext = hdr[l * 4 + 1];
-                        const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
-                        uint64_t par = 0;
-                        switch (dl) {
-#define LDPC_LDSP_CASE(D) case D + 1: par = ldsp_row_parity<D + 1>(P, pk, z, r); break;
-                            LDPC_LDSP_WIDTHS(LDPC_LDSP_CASE)
-#undef LDPC_LDSP_CASE
-                        default: break;
-                        }
-                        /* hard decision of the layer's external column: its posterior is in my record */
-                        if (ext) par ^= __ballot(__uint_as_float(recs[(size_t)l * z].w) < 0.0f);
-                        bad |= par;
-                    }
+            if (a.early_term || time == a.rounds) {
+                /* the rows of the last layer first (their columns are in the iteration's final state like all
+                 * others, but a frame that has not converged nearly always shows it there already): only
+                 * when all of them are even the other layers are looked at.  The row code does not
+                 * keep parities: one layer's worth of reads here is cheaper than an instruction per edge. */
+                uint64_t bad = row ? layer_odd(a.layers - 1) : 0ull;
+                if (!wg_any(bad != 0ull)) {
+                    if (row)
+                        for (int l = 0; l + 1 < a.layers; ++l) bad |= layer_odd(l);
+                    any_bad = wg_any(bad != 0ull) ? 1 : 0;
                 }
-                any_bad = wg_any(bad != 0ull) ? 1 : 0;
             }
             clean = !any_bad;
             if ((clean && a.early_term) || time == a.rounds) break;
@@ -443,7 +466,7 @@ void layered_ldsp_packed_kernel(const LdspArgs a, const int G)
                 uint4 nxt = uint4{0u, 0u, 0u, 0u};
                 if (active && a.layers > 1) nxt = recs[(size_t)ln * z];
                 const int dl = hdr[l * 4], ext = hdr[l * 4 + 1];
-                const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
+                const ldpc_const_i32 pk = pack + (size_t)l * kLdspPackStride;
                 if (active) {
                     uint4 rec;
                     uint32_t par = 0;
@@ -488,7 +511,7 @@ void layered_ldsp_packed_kernel(const LdspArgs a, const int G)
                 if (need) {
                     for (int l = 0; l < a.layers; ++l) {
                         const int dl = hdr[l * 4], ext = hdr[l * 4 + 1];
-                        const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
+                        const ldpc_const_i32 pk = pack + (size_t)l * kLdspPackStride;
                         uint64_t par = 0;
                         switch (dl) {
 #define LDPC_LDSP_CASE(D) case D + 1: par = ldsp_row_parity<D + 1>(P, pk, z, r); break;
@@ -795,7 +818,7 @@ void flood_ldsp_kernel(const LdspArgs a)
                 uint4 nxt = uint4{0u, 0u, 0u, 0u};
                 if (row && a.layers > 1 && (time > 0 || ln == 0)) nxt = recs[(size_t)ln * z];
                 const int dl = hdr[l * 4], ext = hdr[l * 4 + 1];
-                const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
+                const ldpc_const_i32 pk = pack + (size_t)l * kLdspPackStride;
                 if (row) {
                     float yext = 0.0f;
                     if (ext) yext = y[hdr[l * 4 + 2] + ldsp_wrap(r, hdr[l * 4 + 3], z)];
@@ -842,7 +865,7 @@ void flood_ldsp_kernel(const LdspArgs a)
                 uint64_t bad = 0;
                 if (row) {
                     for (int l = 0; l < a.layers; ++l) {
-                        const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
+                        const ldpc_const_i32 pk = pack + (size_t)l * kLdspPackStride;
                         uint64_t par = 0;
                         switch (hdr[l * 4]) {
 #define LDPC_LDSP_CASE(D) case D: par = ldsp_flood_parity<D, CHAIN>(Pb, pk, z, r); break;
@@ -933,7 +956,7 @@ void flood_ldsp_packed_kernel(const LdspArgs a, const int G)
                 uint4 nxt = uint4{0u, 0u, 0u, 0u};
                 if (active && a.layers > 1 && (time > 0 || ln == 0)) nxt = recs[(size_t)ln * z];
                 const int d = hdr[l * 4];
-                const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
+                const ldpc_const_i32 pk = pack + (size_t)l * kLdspPackStride;
                 if (active) {
                     uint4 rec = cur;
                     uint64_t pm = 0, em = 0;
@@ -965,7 +988,7 @@ void flood_ldsp_packed_kernel(const LdspArgs a, const int G)
                 uint64_t bad = 0;
                 if (need) {
                     for (int l = 0; l < a.layers; ++l) {
-                        const ldpc_const_i32 pk = pack + (size_t)l * (2 * kLdspMaxDeg);
+                        const ldpc_const_i32 pk = pack + (size_t)l * kLdspPackStride;
                         switch (hdr[l * 4]) {
 #define LDPC_LDSP_CASE(D) case D: bad |= ldsp_flood_parity<D, CHAIN>(Pb, pk, z, r); break;
                             LDPC_LDSP_WIDTHS1(LDPC_LDSP_CASE)
@@ -1070,7 +1093,7 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
     for (int32_t b : bc) ++deg[b];
     const bool will_pack = z <= 32 && !tune_forced_off(tune.ldsp_pack);
     const bool allow_ext = !tune_forced_off(tune.ldsp_ext) && !(flood && will_pack);   /* the packed flooding kernel keeps every column in LDS */
-    std::vector<int32_t> slot(nb, 0), hdr((size_t)layers * 4, 0), pack((size_t)layers * 2 * kLdspMaxDeg, 0);
+    std::vector<int32_t> slot(nb, 0), hdr((size_t)layers * 4, 0), pack((size_t)layers * kLdspPackStride, 0);
     std::vector<char> external(nb, 0);
     int ext_cols = 0;
     for (int l = 0; l < layers; ++l) {
@@ -1087,8 +1110,12 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
         hdr[l * 4 + 2] = ext ? bc[last] * z : 0;
         hdr[l * 4 + 3] = ext ? sh[last] : 0;
         for (int k = 0; k < d - ext; ++k) {
-            pack[(size_t)l * 2 * kLdspMaxDeg + k] = slot[bc[lp[l] + k]] * z * 4;
-            pack[(size_t)l * 2 * kLdspMaxDeg + kLdspMaxDeg + k] = sh[lp[l] + k] * 4;
+            const int32_t col4 = slot[bc[lp[l] + k]] * z * 4, shift4 = sh[lp[l] + k] * 4;
+            int32_t *row = &pack[(size_t)l * kLdspPackStride];
+            row[k] = col4;
+            row[kLdspMaxDeg + k] = shift4;
+            row[2 * kLdspMaxDeg + k] = col4 + shift4;
+            row[3 * kLdspMaxDeg + k] = z * 4 - shift4;
         }
     }
     int mw = (z + 63) / 64;
