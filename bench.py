@@ -406,9 +406,9 @@ def main():
                 traffic = None
         probe = None
         try:
-            probe = L.capi.hbm_probe(local_rank, 1 << 30, 5)
+            probe, probe_default, probe_nt = L.capi.hbm_probe(local_rank, 1 << 30, 5, by_policy=True)
         except Exception:
-            probe = None
+            probe = probe_default = probe_nt = None
         step_alg = (16 * g.E + 4 * N_CODE) * ITERS * B
         res = {
             "metric": "decoded Mbit/s (info bits), DVB-S2 N=64800 rate-1/2, 50 iters",
@@ -445,7 +445,11 @@ def main():
                 "two_kernel_formulation": {      # the same launch priced at its share of 16 E + 4 N
                     "bytes_per_launch": int(dom_alg), "achieved": round(dom_alg / (dom_avg_ms * 1e-3) / 1e9, 1),
                     "frac": round(dom_alg / (dom_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                # float4 copy of 1 GiB in this process: the better of the default cache policy and the
+                # streaming kernels' non-temporal one (both listed)
                 "hbm_probe_gbs": None if probe is None else round(probe, 1),
+                "hbm_probe_by_policy": None if probe is None else {"default": round(probe_default, 1),
+                                                                   "nontemporal": round(probe_nt, 1)},
                 "frac_of_probe": None if not probe else round(achieved / probe, 4),
                 "all_flooding_kernels": {
                     "moved_achieved": round(all_moved / (all_ms * 1e-3) / 1e9, 1),

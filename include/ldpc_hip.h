@@ -223,7 +223,9 @@ typedef struct ldpc_kernel_time {
                               read or written + 4 B per channel value read, per frame    */
     char name[64];         /* e.g. "check_link_kernel<sp,7,4>" (algo, degree, frames/lane), the
                               kernel's name in a rocprofv3 trace up to the spelling of the
-                              template arguments                                        */
+                              template arguments; the one-launch record kernels carry their
+                              launch shape instead: "layered_ldsp_kernel[768x384,1]" =
+                              [persistent grid x workgroup size, frames per workgroup]  */
     int64_t bytes_moved;   /* bytes those launches' own loads and stores move: = bytes_total except
                               for the column-fused check kernel, whose fused columns' messages
                               never travel through HBM (the figure the PMC counters confirm)  */
@@ -258,10 +260,12 @@ int ldpc_count_errors_device(const uint8_t *out_dev, const uint8_t *ref_dev, int
                              int64_t bytes_per_frame, int64_t errors[3], int32_t device, void *stream);
 
 /* ---- measurement aid: the rate a plain float4 copy of `bytes` bytes (read + write counted)
- *      sustains on `device` right now, best of `reps` launches, HIP-event timed on a stream of its
- *      own.  The benchmark reports it next to its roofline figures so that a kernel's fraction of
+ *      sustains on `device` right now, best of `reps` launches each with the default cache policy
+ *      and with non-temporal loads and stores (the streaming kernels' policy), HIP-event timed on
+ *      a stream of its own.  *copy_gbs = the better of the two; by_policy (may be NULL) receives
+ *      {default, non-temporal}.  The benchmark reports it next to its roofline figures so that a kernel's fraction of
  *      the 8 TB/s specification can also be read against what the box at hand delivers. */
-int ldpc_hbm_probe_device(int32_t device, int64_t bytes, int32_t reps, double *copy_gbs);
+int ldpc_hbm_probe_device(int32_t device, int64_t bytes, int32_t reps, double *copy_gbs, double *by_policy);
 
 #ifdef __cplusplus
 }

@@ -109,7 +109,7 @@ def load():
                                    ctypes.c_int64, ctypes.c_int32, vp]
     L.ldpc_count_errors_device.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, i64p, ctypes.c_int32, vp]
     L.ldpc_hbm_probe_device.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32,
-                                        ctypes.POINTER(ctypes.c_double)]
+                                        ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     _lib = L
     return L
 

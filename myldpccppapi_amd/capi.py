@@ -43,11 +43,13 @@ def apply_tune(cfg, tune):
     cfg.tune_flags, cfg.tune_ldsp_shape = flags, shape
 
 
-def hbm_probe(device=0, nbytes=1 << 30, reps=5):
-    """GB/s of a plain float4 copy on `device` (read + write), best of `reps`."""
+def hbm_probe(device=0, nbytes=1 << 30, reps=5, by_policy=False):
+    """GB/s of a plain float4 copy on `device` (read + write), best of `reps` launches with the default
+    cache policy and `reps` with non-temporal loads and stores; by_policy=True: (best, default, nt)."""
     g = ctypes.c_double(0.0)
-    _lib.check(_lib.load().ldpc_hbm_probe_device(int(device), int(nbytes), int(reps), ctypes.byref(g)))
-    return g.value
+    two = (ctypes.c_double * 2)(0.0, 0.0)
+    _lib.check(_lib.load().ldpc_hbm_probe_device(int(device), int(nbytes), int(reps), ctypes.byref(g), two))
+    return (g.value, two[0], two[1]) if by_policy else g.value
 
 
 def tune_from_env(env=None):

@@ -21,8 +21,8 @@ os.makedirs(dst, exist_ok=True)
 
 def short(name):
     name = re.sub(r"^void ", "", name)
-    name = re.sub(r"\(.*$", "", name)
     name = name.replace("ldpc::", "").replace("(anonymous namespace)::", "")
+    name = re.sub(r"\(.*$", "", name)
     if len(name) > 80:
         name = name[:77] + "..."
     return name
