@@ -386,3 +386,13 @@ def test_cpp_coder_round_trip_with_frames_not_byte_aligned(built, tmp_path):
             # writes K/8 whole bytes), so the only differences are the two orphan bytes
             assert bad.tolist() == [80, 161], (mode, batch, bad)
             assert got[80] == 0 and got[161] == 0
+
+
+def test_hbm_probe_reports_both_cache_policies(built):
+    """ldpc_hbm_probe_device: a 256 MiB float4 copy with the default cache policy and with non-temporal
+    accesses; the headline figure is the better of the two and both are plausible HBM rates."""
+    best, plain, nt = L.capi.hbm_probe(0, 256 << 20, 3, by_policy=True)
+    assert best == max(plain, nt)
+    assert 1000.0 < plain < 8000.0 and 1000.0 < nt < 8000.0, (plain, nt)
+    with pytest.raises(L.LdpcError):
+        L.capi.hbm_probe(0, 1 << 10, 3)                                     # below 1 MiB: refused
