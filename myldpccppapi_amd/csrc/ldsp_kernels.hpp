@@ -327,7 +327,7 @@ void layered_ldsp_kernel(const LdspArgs a)
                 const int ln = l + 1 < a.layers ? l + 1 : 0;
                 /* by every lane, outside any branch: a conditional request makes the compiler copy the
                  * registers, and wait for them, where the branch ends -- at once.  Lanes beyond the last row
-                 * read their neighbours' records (the rings end with 64 spare ones). */
+                 * read their neighbours' records (the rings end with spare ones). */
                 uint4 nxt = recs[(size_t)ln * z];
                 const int dl = hdr[l * 4], ext = hdr[l * 4 + 1];
                 const ldpc_const_i32 pk = pack + (size_t)l * kLdspPackStride;
@@ -1164,9 +1164,9 @@ inline hipError_t ldsp_plan_create(LdspPlan *pl, int32_t M, int32_t N, int64_t E
     pl->per_cu = per_cu;
     pl->grid = (int32_t)std::min<int64_t>((std::max<int64_t>(max_batch, 1) + pl->wg_frames - 1) / pl->wg_frames, (int64_t)per_cu * cus);
     if (tune.ldsp_grid) pl->grid = std::max(1, std::min(pl->grid, tune.ldsp_grid));
-    /* + 64: lanes beyond the last row request records too (never used) */
-    if ((e = hipMalloc((void **)&pl->recs, ((size_t)pl->grid * pl->wg_frames * M + 64) * sizeof(uint4)))) return e;
-    if ((e = hipMalloc((void **)&pl->zf, ((size_t)pl->grid * pl->wg_frames * M + 64) * sizeof(uint32_t)))) return e;
+    /* + 1024 (the largest workgroup): lanes beyond the last row request records too (never used) */
+    if ((e = hipMalloc((void **)&pl->recs, ((size_t)pl->grid * pl->wg_frames * M + 1024) * sizeof(uint4)))) return e;
+    if ((e = hipMalloc((void **)&pl->zf, ((size_t)pl->grid * pl->wg_frames * M + 1024) * sizeof(uint32_t)))) return e;
     pl->eligible = true;
     return hipSuccess;
 }
