@@ -164,6 +164,43 @@ def host_path(g, groups=3, B=BATCH_PER_GPU):
                     % (frames, groups, B, ITERS, len(times))}
 
 
+def streams_overlap(g, B, steps, warmup, algo, device=0):
+    """The headline workload with the batch cut into 2 and 4 frame ranges on streams of their own
+    (ldpc_decoder_config.streams): one range's kernels fill the GPU while another's kernel drains.  Same
+    frames, same bytes (checked against the single-stream output); reported beside the headline, whose
+    per-launch durations are only meaningful for kernels that run alone."""
+    import torch
+    import myldpccppapi_amd as L
+    from myldpccppapi_amd import channel
+    y = channel.awgn_device(N_CODE, 0, B, SIGMA, seed=SEED, device=device)
+    out = torch.empty(L.out_bytes(K_CODE, B), dtype=torch.uint8, device="cuda")
+    res, ref = {}, None
+    for streams in (1, 2, 4):
+        dec = L.Decoder(g, K_CODE, max_batch=B, algo=algo, max_iter=ITERS, llr_scale=8.0, early_term=True,
+                        device=device, streams=streams)
+        s = torch.cuda.current_stream().cuda_stream
+        for _ in range(max(1, warmup)):
+            dec.decode_device(y.data_ptr(), B, out.data_ptr(), out.numel(), None, s)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            dec.decode_device(y.data_ptr(), B, out.data_ptr(), out.numel(), None, s)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        o = out.cpu()
+        if ref is None:
+            ref = o
+        res[str(streams)] = {"value": round(B * K_CODE / dt / 1e6, 2), "unit": "Mbit/s", "ms_per_step": round(dt * 1e3, 3),
+                             "same_bytes_as_one_stream": bool(torch.equal(o, ref))}
+        dec.close()
+        del dec
+        torch.cuda.empty_cache()
+    res["what"] = ("the headline step (%d frames, %d iterations, %s) with ldpc_decoder_config.streams = 1, 2, 4: sub-decoders "
+                   "of %d / streams frames each on a stream of its own, same device; `steps` = %d untimed-kernel steps each"
+                   % (B, ITERS, algo, B, steps))
+    return res
+
+
 def ber_points(g, B=BATCH_PER_GPU):
     """BER @ SNR on the headline code, reference convention (Test.cpp:56-57: BPSK +-1, sd =
     10^(-SNR_dB/20)), all-zero codeword, channel and error count on the GPU: one batch per point."""
@@ -492,6 +529,10 @@ def main():
                 except Exception as e:      # an extra point must never cost the headline line
                     extra[key] = {"error": repr(e)}
             res["extra"] = extra
+            try:
+                res["streams"] = streams_overlap(g, B, max(3, args.steps // 2), 1, args.algo, local_rank)
+            except Exception as e:
+                res["streams"] = {"error": repr(e)}
             try:
                 res["ber"] = ber_points(g)
             except Exception as e:

@@ -76,6 +76,10 @@ public:
      * ranges side by side, batchSize frames per device and launch group; bytes identical to the
      * single-device result.  Before addDecodeType(). */
     void setDevices(const int *ordinals, int count) { devices.assign(ordinals, ordinals + (count > 0 ? count : 0)); }
+    /* 2..8: every decoder cuts its launch group into that many frame ranges on streams of their own, same
+     * device (ldpc_decoder_config.streams: launch boundaries overlap; needs batchSize >= 512 per stream and
+     * K % 8 == 0, else one stream).  Before addDecodeType(). */
+    void setStreams(int n) { streams = n; }
     int lastIterations() const { return lastTime; }             /* the reference's "Time=" */
     const char *lastError() const { return err.c_str(); }
     int getNonZeros() const { return nonZeros; }
@@ -94,6 +98,7 @@ private:
     float llrScale;
     int device;
     std::vector<int> devices;        /* setDevices(); empty: `device` alone */
+    int streams = 0;                 /* setStreams() */
     int makeDecoder(const ldpc_decoder_config &cfg, ldpc_decoder **out);
     const signed char *hSeed;
     int seedRowLength;

@@ -112,7 +112,13 @@ typedef struct ldpc_decoder_config {
                                    (default and maximum 512); -1 = off                            */
     int32_t tune_ldsp_grid;     /* record kernels (ldsp_kernels.hpp): persistent workgroups        */
     int32_t tune_ldsp_shape;    /* workgroups per CU | waves per workgroup << 8                    */
-    int32_t reserved;           /* must be 0                                                       */
+    int32_t streams;            /* 0 / 1: one decode stream.  2..8: the batch is cut into that many
+                                   contiguous frame ranges (multiples of 256 frames), each decoded by a
+                                   sub-decoder of its own on a stream of its own, on the same device:
+                                   the kernels of one range fill the GPU while another range's kernel
+                                   drains (launch boundaries cost 8 % of the headline step).  Same bytes
+                                   and iteration counts; ignored when max_batch < 512 per stream or K % 8 != 0.  Not a
+                                   tuning field of kernels: a property of the handle                  */
 } ldpc_decoder_config;
 
 /* two-bit fields of tune_flags: LDPC_TUNE_ON(f) forces the choice on, LDPC_TUNE_OFF(f) off */

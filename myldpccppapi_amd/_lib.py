@@ -33,7 +33,7 @@ class DecoderConfig(ctypes.Structure):
                 ("tune_flags", ctypes.c_int32), ("tune_rows_per_wave", ctypes.c_int32),
                 ("tune_cols_per_wave", ctypes.c_int32), ("tune_link_rows", ctypes.c_int32),
                 ("tune_compact", ctypes.c_int32), ("tune_ldsp_grid", ctypes.c_int32),
-                ("tune_ldsp_shape", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("tune_ldsp_shape", ctypes.c_int32), ("streams", ctypes.c_int32)]
 
 
 class DecodeStats(ctypes.Structure):

@@ -136,7 +136,7 @@ class Decoder:
 
     def __init__(self, graph, K, max_batch, algo="sp", max_iter=40, llr_scale=8.0, early_term=True,
                  device=0, layer_rows=0, pack_mode=PACK_BYTES, frames_per_lane=0, poll_interval=0,
-                 msg_dtype=MSG_F32, tune=None, devices=None):
+                 msg_dtype=MSG_F32, tune=None, devices=None, streams=0):
         L = _lib.load()
         cfg = DecoderConfig()
         L.ldpc_decoder_config_init(ctypes.byref(cfg))
@@ -147,6 +147,7 @@ class Decoder:
         cfg.early_term, cfg.device, cfg.layer_rows = int(bool(early_term)), int(device), int(layer_rows)
         cfg.pack_mode, cfg.frames_per_lane, cfg.poll_interval = int(pack_mode), int(frames_per_lane), int(poll_interval)
         apply_tune(cfg, tune)
+        cfg.streams = int(streams)      # > 1: sub-decoders on streams of their own, same device (ldpc_hip.h)
         self.cfg = cfg
         self.graph = graph
         self.K, self.N, self.E = int(K), graph.N, graph.E

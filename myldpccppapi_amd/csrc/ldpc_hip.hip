@@ -274,9 +274,15 @@ struct ldpc_decoder {
     /* a handle over several devices (ldpc_decoder_create_multi): one single-device decoder per entry
      * of the device list; this object then owns no device state of its own */
     std::vector<ldpc_decoder *> shards;
+    /* cfg.streams > 1: the shards are sub-decoders on ONE device, each with max_batch / streams frames and
+     * its own stream; such a handle also takes device pointers (ldpc_decode_device) */
+    bool one_device = false;
+    int64_t shard_frames = 0;           /* frames a sub-decoder holds */
+    hipEvent_t ev_in = nullptr;         /* the caller's stream at the start of a device-pointer call */
 
     ~ldpc_decoder()
     {
+        if (ev_in) (void)hipEventDestroy(ev_in);
         for (ldpc_decoder *sh : shards) (void)ldpc_decoder_destroy(sh);
         for (auto &s : spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
         if (ev_begin) (void)hipEventDestroy(ev_begin);
@@ -950,13 +956,39 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     if (cfg->msg_dtype == LDPC_MSG_F16 && cfg->algo != LDPC_ALGO_MS)
         return fail(LDPC_ERR_UNSUPPORTED, "fp16 messages are built for flooding min-sum only "
                     "(the probability-domain SP needs fp32 range; layered: not yet)");
-    if (!ldpc::tune_valid(*cfg)) return fail(LDPC_ERR_ARG, "tuning / reserved config fields out of range");
+    if (!ldpc::tune_valid(*cfg)) return fail(LDPC_ERR_ARG, "tuning / streams config fields out of range");
 
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev)
         return fail(LDPC_ERR_HIP, "device %d not present (%d HIP devices)", cfg->device, ndev);
     HIP_TRY(hipSetDevice(cfg->device));
+
+    /* several streams: a handle over sub-decoders of max_batch / streams frames (whole tiles of any
+     * layout: multiples of 256 frames).  Not for K % 8 != 0, where a frame's first byte depends on the
+     * launch group it falls into (shard_unit below). */
+    if (cfg->streams > 1 && (int64_t)cfg->max_batch >= 512 * (int64_t)cfg->streams && cfg->K % 8 == 0 && !t_creating_child) {
+        const int64_t per = (((int64_t)cfg->max_batch + cfg->streams - 1) / cfg->streams + 255) / 256 * 256;
+        ldpc_decoder *grp = new (std::nothrow) ldpc_decoder;
+        if (!grp) return fail(LDPC_ERR_NOMEM, "out of memory");
+        std::unique_ptr<ldpc_decoder> guard(grp);
+        for (int32_t i = 0; i < cfg->streams; ++i) {
+            ldpc_decoder_config c = *cfg;
+            c.streams = 0;
+            c.max_batch = (int32_t)per;
+            ldpc_decoder *sh = nullptr;
+            const int rc = ldpc_decoder_create(g, &c, &sh);
+            if (rc) return rc;                   /* the guard destroys the sub-decoders made so far */
+            grp->shards.push_back(sh);
+        }
+        grp->cfg = *cfg;
+        grp->M = g->M; grp->N = g->N; grp->E = g->E;
+        grp->one_device = true;
+        grp->shard_frames = per;
+        HIP_TRY(hipEventCreateWithFlags(&grp->ev_in, hipEventDisableTiming));
+        *out = guard.release();
+        return LDPC_OK;
+    }
 
     ldpc_decoder *d = new (std::nothrow) ldpc_decoder;
     if (!d) return fail(LDPC_ERR_NOMEM, "out of memory");
@@ -1169,6 +1201,7 @@ int ldpc_decoder_create_multi(const ldpc_graph *g, const ldpc_decoder_config *cf
     for (int32_t i = 0; i < n_devices; ++i) {
         ldpc_decoder_config c = *cfg;
         c.device = devices[i];
+        c.streams = 0;                           /* a device list is the one level of ranges */
         ldpc_decoder *sh = nullptr;
         const int rc = ldpc_decoder_create(g, &c, &sh);
         if (rc) return rc;                       /* the guard destroys the shards made so far */
@@ -1181,13 +1214,79 @@ int ldpc_decoder_create_multi(const ldpc_graph *g, const ldpc_decoder_config *cf
     return LDPC_OK;
 }
 
+/* cfg.streams > 1: the frames are cut into one contiguous range per sub-decoder; every sub-decoder's
+ * stream first waits for the caller's stream (its input is ready), and the caller's stream then waits for
+ * every sub-decoder's last kernel, so the call keeps ldpc_decode_device's stream-ordered meaning.  A
+ * sub-decoder that polls (poll_interval > 0) blocks its host thread: each range gets a thread of its own,
+ * as the device-list path does; asynchronous ranges are simply enqueued one after the other. */
+static int decode_device_streams(ldpc_decoder *d, const float *llr_dev, int64_t frames, uint8_t *out_dev,
+                                 int64_t out_bytes, int32_t *iters_dev, void *stream)
+{
+    const int n = (int)d->shards.size();
+    if (frames < 0 || frames > d->cfg.max_batch)
+        return fail(LDPC_ERR_ARG, "frames=%lld outside [0, max_batch=%d]", (long long)frames, d->cfg.max_batch);
+    for (int i = 0; i < n; ++i) d->shards[i]->have_last = false;
+    if (frames == 0) { d->last_frames = 0; d->have_last = false; return LDPC_OK; }
+    if (!llr_dev) return fail(LDPC_ERR_ARG, "llr is NULL");
+    const int64_t need = ldpc_out_bytes(d->cfg.K, frames, d->cfg.pack_mode);
+    if (out_dev && out_bytes < need && d->cfg.pack_mode == LDPC_PACK_BITS)
+        return fail(LDPC_ERR_ARG, "out_bytes=%lld < %lld", (long long)out_bytes, (long long)need);
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipEventRecord(d->ev_in, s));
+    std::vector<int64_t> lo((size_t)n), hi((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const int rc = ldpc_shard_range(frames, i, n, 256, &lo[i], &hi[i]);
+        if (rc) return rc;
+    }
+    std::vector<int> rcs((size_t)n, LDPC_OK);
+    std::vector<std::string> errs((size_t)n);
+    auto work = [&](int i) {
+        ldpc_decoder *sh = d->shards[i];
+        if (hi[i] <= lo[i]) return;
+        if (hipSetDevice(d->cfg.device) != hipSuccess || hipStreamWaitEvent(sh->stream, d->ev_in, 0) != hipSuccess) {
+            rcs[i] = fail(LDPC_ERR_HIP, "stream %d: cannot wait for the caller's stream", i);
+            errs[i] = g_err;
+            return;
+        }
+        const int64_t base = lo[i] * (int64_t)d->cfg.K / 8;      /* exact: lo is a multiple of 256 */
+        const int64_t room = std::max<int64_t>(0, out_bytes - base);
+        rcs[i] = ldpc_decode_device(sh, llr_dev + (size_t)lo[i] * d->N, hi[i] - lo[i], out_dev ? out_dev + base : nullptr,
+                                    std::min(room, ldpc_out_bytes(d->cfg.K, hi[i] - lo[i], d->cfg.pack_mode)),
+                                    iters_dev ? iters_dev + lo[i] : nullptr, sh->stream);
+        if (rcs[i]) errs[i] = g_err;
+    };
+    std::vector<std::thread> threads;
+    std::vector<int> inline_work;
+    const bool blocking = d->cfg.poll_interval > 0 && d->cfg.early_term;
+    for (int i = 1; i < n; ++i) {
+        if (hi[i] <= lo[i]) continue;
+        if (!blocking) { inline_work.push_back(i); continue; }
+        try { threads.emplace_back(work, i); }
+        catch (...) { inline_work.push_back(i); }
+    }
+    work(0);
+    for (int i : inline_work) work(i);
+    for (auto &t : threads) t.join();
+    /* the caller's stream continues when every range is done (also after an error: what was enqueued runs) */
+    for (int i = 0; i < n; ++i)
+        if (hi[i] > lo[i] && d->shards[i]->have_last) (void)hipStreamWaitEvent(s, d->shards[i]->ev_end, 0);
+    for (int i = 0; i < n; ++i)
+        if (rcs[i]) { g_err = errs[i]; return rcs[i]; }
+    d->have_last = true;
+    d->last_frames = frames;
+    d->last_stream = s;
+    return LDPC_OK;
+}
+
 int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, uint8_t *out_dev,
                        int64_t out_bytes, int32_t *iters_dev, void *stream)
 {
     if (!d) return fail(LDPC_ERR_ARG, "decoder is NULL");
-    if (!d->shards.empty())
+    if (!d->shards.empty() && !d->one_device)
         return fail(LDPC_ERR_STATE, "a multi-device handle decodes host buffers only (ldpc_decode): device "
                     "pointers belong to one device");
+    if (!d->shards.empty()) return decode_device_streams(d, llr_dev, frames, out_dev, out_bytes, iters_dev, stream);
     if (frames < 0 || frames > d->cfg.max_batch)
         return fail(LDPC_ERR_ARG, "frames=%lld outside [0, max_batch=%d]", (long long)frames,
                     d->cfg.max_batch);

@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# a glibc abort message (heap check, assert) goes to stderr, i.e. into the test log, not to a terminal
+os.environ.setdefault("LIBC_FATAL_STDERR_", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -201,3 +201,67 @@ def test_caller_locked_input_is_copied_directly(built):
             out, iters = dec.decode(src)
             assert np.array_equal(out, want["out"]) and np.array_equal(iters, want["iters"]), devs
         dec.close()
+
+
+@pytest.mark.parametrize("algo,poll", [("sp", 0), ("ms", 2), ("layered", 0)])
+def test_streams_on_one_device_equal_the_single_stream_decoder(built, algo, poll):
+    """cfg.streams = 2 / 3: sub-decoders of max_batch / streams frames on streams of their own (same GPU);
+    device-pointer calls (asynchronous and polled) and the host-buffer call must give the single-stream
+    decoder's bytes and iteration counts for full, ragged and tiny batches, and the caller's stream must
+    see the result in stream order (the copies below are enqueued on it right after the call)."""
+    import torch
+    g, og, K, M, z = _graph(codes.RATE_1_2, 2304)
+    B = 2048
+    y = channel.awgn_device(2304, 0, B, 0.8, seed=61, device=0)
+    yh = y.cpu().numpy()
+    one = L.Decoder(g, K, max_batch=B, algo=algo, max_iter=20, layer_rows=z, poll_interval=poll,
+                    tune={"fused": False, "ldsp": False} if algo != "layered" else None)
+    want = {}
+    for n in (B, 1500, 300, 1):
+        want[n] = one.decode(yh[:n])
+    sample = oracle.decode(og, yh[:64], algo, max_iter=20, layer_rows=z)
+    assert np.array_equal(want[B][0][:64 * K // 8], sample["out"]) and np.array_equal(want[B][1][:64], sample["iters"])
+    one.close()
+    for streams in (2, 3):
+        dec = L.Decoder(g, K, max_batch=B, algo=algo, max_iter=20, layer_rows=z, poll_interval=poll, streams=streams,
+                        tune={"fused": False, "ldsp": False} if algo != "layered" else None)
+        s = torch.cuda.Stream()
+        for n in (B, 1500, 300, 1, B):
+            out = torch.zeros(L.out_bytes(K, n), dtype=torch.uint8, device="cuda")
+            it = torch.zeros(n, dtype=torch.int32, device="cuda")
+            with torch.cuda.stream(s):
+                dec.decode_device(y.data_ptr(), n, out.data_ptr(), out.numel(), it.data_ptr(), s.cuda_stream)
+                o, i = out.cpu().numpy(), it.cpu().numpy()          # stream-ordered behind the call
+            assert np.array_equal(o, want[n][0]) and np.array_equal(i, want[n][1]), (streams, n)
+            st = dec.stats()
+            assert st["frames"] == n and st["batch_time"] == int(want[n][1].max())
+        oh, ih = dec.decode(yh[:1500])
+        assert np.array_equal(oh, want[1500][0]) and np.array_equal(ih, want[1500][1]), streams
+        dec.close()
+    # too small a batch per stream, or frames that are not byte aligned: one plain decoder behind the handle
+    small = L.Decoder(g, K, max_batch=600, algo=algo, max_iter=20, layer_rows=z, streams=2)
+    o, i = small.decode(yh[:300])
+    assert np.array_equal(o, want[300][0]) and np.array_equal(i, want[300][1])
+    small.close()
+
+
+def test_cpp_coder_with_streams(built, tmp_path):
+    """Coder::setStreams(2): 1100 frames of the (2304, 1152) code in launch groups of 1024, each group cut
+    into two ranges on streams of their own; decoded bytes equal the plain Coder's on the same noisy stream
+    (host polling on: each range has a host thread)."""
+    exe = str(tmp_path / "coder_roundtrip")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "coder_roundtrip.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "myldpccppapi_amd"), "-lmyldpc", "-lldpc_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "myldpccppapi_amd")])
+    for mode in ("SP", "MS"):
+        outs = []
+        for streams in (0, 2):
+            pre = str(tmp_path / ("s%s_%d" % (mode, streams)))
+            cmd = [exe, "0", "2304", str(1100 * 144), "1024", "2.6", mode, "11", "--dump", pre]
+            if streams:
+                cmd += ["--streams", str(streams)]
+            out = subprocess.run(cmd, capture_output=True, text=True)
+            assert out.returncode == 0 and "ParityFail=0" in out.stdout, out.stdout + out.stderr
+            outs.append(open(pre + ".out", "rb").read())
+        assert outs[0] == outs[1], mode

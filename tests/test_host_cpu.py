@@ -123,7 +123,7 @@ def test_tuning_fields_are_validated_and_no_environment_is_read(built):
     g = L.Graph(rows, cols, 324, 648)
     lib = _lib.load()
     for field, value in (("tune_flags", 3), ("tune_flags", 1 << 26), ("tune_rows_per_wave", -1), ("tune_link_rows", -2),
-                         ("tune_compact", -2), ("tune_ldsp_shape", 1 << 16), ("reserved", 1)):
+                         ("tune_compact", -2), ("tune_ldsp_shape", 1 << 16), ("streams", 9), ("streams", -1)):
         cfg = _lib.DecoderConfig()
         lib.ldpc_decoder_config_init(ctypes.byref(cfg))
         cfg.K, cfg.max_batch = 324, 4
