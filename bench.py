@@ -56,7 +56,7 @@ EXTRA_CONFIGS = {
 }
 
 
-def measure_extra(name, steps, warmup, batch=0, sigma=0.0, fpl=0, poll=-1, tune=None):
+def measure_extra(name, steps, warmup, batch=0, sigma=0.0, fpl=0, poll=-1, tune=None, streams=0):
     """One extra config on the current GPU: dict with the headline fields of its own."""
     import numpy as np
     import torch
@@ -80,7 +80,10 @@ def measure_extra(name, steps, warmup, batch=0, sigma=0.0, fpl=0, poll=-1, tune=
         c = dict(c, poll=poll, desc=c["desc"] + " [poll_interval %d]" % poll)
     g = L.Graph(rows, cols, M, N)
     dec = L.Decoder(g, K, max_batch=B, algo=c["algo"], max_iter=c["iters"], early_term=c["early"],
-                    layer_rows=layer, msg_dtype=c["msg"], poll_interval=c["poll"], frames_per_lane=fpl, tune=tune)
+                    layer_rows=layer, msg_dtype=c["msg"], poll_interval=c["poll"], frames_per_lane=fpl, tune=tune,
+                    streams=streams)
+    if streams > 1:
+        c = dict(c, desc=c["desc"] + " [%d streams]" % streams)
     y = channel.awgn_device(N, 0, B, c["sigma"], seed=SEED)
     out = torch.empty(L.out_bytes(K, B), dtype=torch.uint8, device="cuda")
     it = torch.empty(B, dtype=torch.int32, device="cuda")
@@ -326,6 +329,7 @@ def main():
     ap.add_argument("--sigma", type=float, default=0.0, help="extra configs: noise level override")
     ap.add_argument("--fpl", type=int, default=0, help="frames per lane override (tuning)")
     ap.add_argument("--poll", type=int, default=-1, help="extra configs: poll_interval override (0 = asynchronous)")
+    ap.add_argument("--streams", type=int, default=0, help="ldpc_decoder_config.streams (experiments; the headline is single-stream)")
     ap.add_argument("--tune", default="", help='tuning fields as JSON, e.g. \'{"merge": false}\' (A/B experiments)')
     args = ap.parse_args()
 
@@ -356,7 +360,7 @@ def main():
         if world > 1:
             sys.exit("extra configs are single-GPU measurements")
         print(json.dumps(measure_extra(args.config, args.steps, args.warmup, args.batch, args.sigma, args.fpl, args.poll,
-                                       json.loads(args.tune) if args.tune else None)), flush=True)
+                                       json.loads(args.tune) if args.tune else None, args.streams)), flush=True)
         return
 
     import myldpccppapi_amd as L
@@ -367,7 +371,7 @@ def main():
     g = L.Graph(rows, cols, N_CODE - K_CODE, N_CODE)
     dec = L.Decoder(g, K_CODE, max_batch=B, algo=args.algo, max_iter=ITERS, llr_scale=8.0,
                     early_term=True, device=local_rank, frames_per_lane=args.fpl,
-                    tune=json.loads(args.tune) if args.tune else None)
+                    tune=json.loads(args.tune) if args.tune else None, streams=args.streams)
     # synthetic channel: all-zero codeword + AWGN, generated in HBM, distinct per rank
     lo, hi = sharding.shard_range(B * world, rank, world)
     # (counter-based noise, csrc/ldpc_channel.h: frame lo + i of the seed's stream, whatever the world size)
