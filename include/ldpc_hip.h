@@ -138,7 +138,9 @@ enum ldpc_tune_field {
                                    (default: on when early_term && poll_interval == 0)              */
     LDPC_TUNE_MERGE = 20,       /* degree classes of one bucket share a launch (default on)         */
     LDPC_TUNE_LINK_DEEP = 22,   /* column-fused check kernel requests its inputs two rows ahead     */
-    LDPC_TUNE_LINK_HALF = 24    /* column-fused check kernel with 2 values per lane (tiles of 256)  */
+    LDPC_TUNE_LINK_HALF = 24,   /* column-fused check kernel with 2 values per lane (tiles of 256)  */
+    LDPC_TUNE_LINK_GUIDED = 26  /* column-fused check kernel: its launch ends with shorter row chunks
+                                   (default on from 4 tiles)                                         */
 };
 #define LDPC_TUNE_ON(field) (1 << (field))
 #define LDPC_TUNE_OFF(field) (2 << (field))

@@ -569,8 +569,30 @@ struct LinkArgs {
     const int32_t *__restrict__ extra_e0;  /* [n_extra] first edge id */
     const int32_t *__restrict__ extra_deg; /* [n_extra] */
     int32_t n_extra;
-    int32_t link_blocks;                   /* gridDim.x of the linked rows proper */
+    int32_t link_blocks;                   /* blocks (gridDim.y) of the linked rows proper */
+    /* guided chunks: the first n_big row chunks of a tile hold rows_per_wave rows, the rest small_rows.
+     * The grid is (tiles, blocks): tiles vary fastest in dispatch order, so the launch ENDS with the short
+     * chunks of all tiles and its last waves are short ones -- with equal chunks the CUs drain over a whole
+     * chunk's time (16 rows: 176 us of a 1.39 ms launch, half of it lost). */
+    int32_t n_big, small_rows;
 };
+
+/* rows [*rb, *re) of chunk c of a class of n_rows rows (host: fusion lists, grid size; device: the kernels) */
+__host__ __device__ inline void link_chunk_rows(int c, int rows_per_wave, int n_big, int small_rows, int n_rows,
+                                               int *rb, int *re)
+{
+    int b, e;
+    if (c < n_big) { b = c * rows_per_wave; e = b + rows_per_wave; }
+    else { b = n_big * rows_per_wave + (c - n_big) * small_rows; e = b + small_rows; }
+    *rb = b < n_rows ? b : n_rows;
+    *re = e < n_rows ? e : n_rows;
+}
+/* number of chunks */
+__host__ __device__ inline int link_chunk_count(int rows_per_wave, int n_big, int small_rows, int n_rows)
+{
+    const int rest = n_rows - n_big * rows_per_wave;
+    return n_big + (rest > 0 ? (rest + small_rows - 1) / small_rows : 0);
+}
 
 /* the trailing blocks of a linked check launch: one left-over row per wave, V values per lane */
 template <int ALGO, int V, typename T>
@@ -578,7 +600,7 @@ __device__ __forceinline__ void link_extra_rows(const CheckArgs &a, const LinkAr
 {
     constexpr size_t F = 64 * V;
     const int lane = threadIdx.x & 63;
-    const int w = ((int)blockIdx.x - g.link_blocks) * kWavesPerBlock + wave_id_in_block();
+    const int w = ((int)blockIdx.y - g.link_blocks) * kWavesPerBlock + wave_id_in_block();
     if (w >= g.n_extra) return;
     const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
     T *Rt = static_cast<T *>(a.R) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
@@ -596,12 +618,12 @@ __global__ __launch_bounds__(kBlock) LDPC_LINK_WIDE_ATTR void check_link_kernel(
 {
     constexpr size_t F = 64 * V;
     const int lane = threadIdx.x & 63;
-    const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
+    const int tile = tile_select<V>(a.tail, a.done, blockIdx.x);
     if (tile < 0) return;
-    if ((int)blockIdx.x >= g.link_blocks) { link_extra_rows<ALGO, V, T>(a, g, tile); return; }
-    const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
-    const int r_begin = wave * a.rows_per_wave;
-    const int r_end = min(r_begin + a.rows_per_wave, a.n_rows);
+    if ((int)blockIdx.y >= g.link_blocks) { link_extra_rows<ALGO, V, T>(a, g, tile); return; }
+    const int wave = (int)blockIdx.y * kWavesPerBlock + wave_id_in_block();
+    int r_begin, r_end;
+    link_chunk_rows(wave, a.rows_per_wave, g.n_big, g.small_rows, a.n_rows, &r_begin, &r_end);
     const size_t lane_off = (size_t)lane * V;
     const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + lane_off;
     T *Qwt = static_cast<T *>(g.Qw) + (size_t)tile * (size_t)a.E * F + lane_off;
@@ -742,13 +764,13 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow_kernel(const CheckAr
     constexpr int SUBS = V / W;                      /* sub-waves per row chunk */
     constexpr int FB = 64 / SUBS;                    /* bits per field */
     const int lane = threadIdx.x & 63;
-    const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
+    const int tile = tile_select<V>(a.tail, a.done, blockIdx.x);
     if (tile < 0) return;
-    if ((int)blockIdx.x >= g.link_blocks) { link_extra_rows<ALGO, V, T>(a, g, tile); return; }
-    const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
+    if ((int)blockIdx.y >= g.link_blocks) { link_extra_rows<ALGO, V, T>(a, g, tile); return; }
+    const int wave = (int)blockIdx.y * kWavesPerBlock + wave_id_in_block();
     const int sub = wave % SUBS;
-    const int r_begin = (wave / SUBS) * a.rows_per_wave;
-    const int r_end = min(r_begin + a.rows_per_wave, a.n_rows);
+    int r_begin, r_end;
+    link_chunk_rows(wave / SUBS, a.rows_per_wave, g.n_big, g.small_rows, a.n_rows, &r_begin, &r_end);
     const size_t lane_off = (size_t)sub * 64 * W + (size_t)lane * W;
     const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + lane_off;
     T *Qwt = static_cast<T *>(g.Qw) + (size_t)tile * (size_t)a.E * F + lane_off;
@@ -877,13 +899,13 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow2_kernel(const CheckA
     constexpr size_t F = 64 * V;
     constexpr int FB = 64 / V;                       /* bits per field */
     const int lane = threadIdx.x & 63;
-    const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
+    const int tile = tile_select<V>(a.tail, a.done, blockIdx.x);
     if (tile < 0) return;
-    if ((int)blockIdx.x >= g.link_blocks) { link_extra_rows<ALGO, V, T>(a, g, tile); return; }
-    const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
+    if ((int)blockIdx.y >= g.link_blocks) { link_extra_rows<ALGO, V, T>(a, g, tile); return; }
+    const int wave = (int)blockIdx.y * kWavesPerBlock + wave_id_in_block();
     const int sub = wave % V;
-    const int r_begin = (wave / V) * a.rows_per_wave;
-    const int r_end = min(r_begin + a.rows_per_wave, a.n_rows);
+    int r_begin, r_end;
+    link_chunk_rows(wave / V, a.rows_per_wave, g.n_big, g.small_rows, a.n_rows, &r_begin, &r_end);
     const size_t lane_off = (size_t)sub * 64 + lane;
     const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + lane_off;
     T *Qwt = static_cast<T *>(g.Qw) + (size_t)tile * (size_t)a.E * F + lane_off;

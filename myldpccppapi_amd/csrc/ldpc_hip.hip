@@ -143,6 +143,8 @@ struct RowClass {
      * the next list row when both fall in one wave's chunk of link_rpw rows */
     DevBuf<int32_t> link_col, link_pos;
     int linked = 0;          /* number of fused columns */
+    /* guided chunks (flood_kernels.hpp: LinkArgs): n_big chunks of link_rpw rows, then chunks of small_rows */
+    int n_big = 0, small_rows = 1;
 };
 struct ColClass {
     int degree = 0;
@@ -207,6 +209,8 @@ struct ldpc_decoder {
     bool link_calibrated = false;       /* chosen by timing the candidates at creation */
     float link_cal_ms[3] = {0, 0, 0};   /* what the calibration measured per launch: [0] wide, [1] narrow, [2] half */
     int link_rpw = 16;                  /* rows per wave of the fused check kernel; 0 = fusion off */
+    int tune_link_guided = 0;           /* tri-state: shorter row chunks at the end of the fused check launch */
+    int cus = 256;                      /* compute units of the device */
     VarFn var_fn[ldpc::kMaxUnrolledDegree + 1] = {};
 
     ldpc::LayeredPlan layered;          /* LDPC_ALGO_LAYERED, streaming (one launch per layer) */
@@ -466,12 +470,14 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
                                       (it < max_iter ? 2 * rc.linked : 0) + 2 * d->extra_edges) * frames));
             CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree, tr};
             LinkArgs lk{rc.link_col.p, rc.link_pos.p, d->chan.p, d->Q.p, d->hard.p, d->N,
-                        (it < max_iter) ? 1 : 0, d->tap_iter ? 1 : 0, d->extra_e0.p, d->extra_deg.p, d->n_extra, 0};
+                        (it < max_iter) ? 1 : 0, d->tap_iter ? 1 : 0, d->extra_e0.p, d->extra_deg.p, d->n_extra, 0,
+                        rc.n_big, rc.small_rows};
             a.rows_per_wave = d->link_rpw;
             const int variant = (d->tune_link_narrow == 2 && !d->link_half_fn[rc.degree]) ? 1 : d->tune_link_narrow;
-            const int waves = ((rc.count + d->link_rpw - 1) / d->link_rpw) * (variant == 1 ? V : variant == 2 ? V / 2 : 1);
+            const int waves = link_chunk_count(d->link_rpw, rc.n_big, rc.small_rows, rc.count) * (variant == 1 ? V : variant == 2 ? V / 2 : 1);
             lk.link_blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
-            dim3 grid(lk.link_blocks + (d->n_extra + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
+            /* tiles vary fastest: the short chunks of all tiles are the launch's last blocks */
+            dim3 grid(tiles, lk.link_blocks + (d->n_extra + kWavesPerBlock - 1) / kWavesPerBlock);
             (variant == 2 ? d->link_half_fn : variant == 1 ? (d->tune_link_deep ? d->link_deep_fn : d->link_narrow_fn) : d->link_fn)
                 [rc.degree]<<<grid, kBlock, 0, s>>>(a, lk);
             HIP_TRY(span_end(d, s));
@@ -615,9 +621,27 @@ int build_classes(ldpc_decoder *d, const ldpc_graph *g)
         const std::vector<int32_t> &ids = rowids_by_deg[kv.first];
         const int rpw = d->link_rpw;
         if (rpw >= 2 && rc.degree >= 2 && rc.degree <= ldpc::kMaxUnrolledDegree) {
+            /* Guided chunks: what the chip holds at once (16 waves per CU) is the launch's last
+             * generation of waves; that many chunks per tile, at the end of the row list, are cut to
+             * a quarter of the rows (>= 2), so that the launch drains over a short chunk's time.  With
+             * fewer than 4 tiles everything would be "last generation": equal chunks then. */
+            rc.n_big = (rc.count + rpw - 1) / rpw;
+            rc.small_rows = rpw;
+            const int small = std::max(2, rpw / 4);
+            if (d->T >= 4 && small < rpw && !ldpc::tune_forced_off(d->tune_link_guided)) {
+                const int64_t last_generation = (int64_t)d->cus * 16 / d->T;       /* chunks per tile */
+                const int64_t big = (int64_t)rc.n_big - last_generation;
+                if (big > 0) { rc.n_big = (int)big; rc.small_rows = small; }
+            }
+            std::vector<char> chunk_end((size_t)rc.count, 0);
+            for (int c = 0, nc = ldpc::link_chunk_count(rpw, rc.n_big, rc.small_rows, rc.count); c < nc; ++c) {
+                int rb, re;
+                ldpc::link_chunk_rows(c, rpw, rc.n_big, rc.small_rows, rc.count, &rb, &re);
+                if (re > rb) chunk_end[(size_t)re - 1] = 1;
+            }
             std::vector<int32_t> lcol((size_t)rc.count, -1), lpos((size_t)rc.count, 0);
             for (int idx = 0; idx + 1 < rc.count; ++idx) {
-                if (idx % rpw == rpw - 1) continue;            /* next row belongs to another wave */
+                if (chunk_end[idx]) continue;                  /* next row belongs to another wave */
                 const int32_t m = ids[idx], m2 = ids[idx + 1];
                 for (int32_t p = g->row_ptr[m]; p < g->row_ptr[m + 1]; ++p) {
                     const int32_t c = g->cols[p];
@@ -797,11 +821,12 @@ template <int V> int calibrate_link(ldpc_decoder *d)
     for (int rep = 0; rep < 4 && err == hipSuccess; ++rep) {
         for (int nar = 0; nar < candidates && err == hipSuccess; ++nar) {
             CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, d->link_rpw, rc.degree, TailRef{nullptr, 0, 0}};
-            LinkArgs lk{rc.link_col.p, rc.link_pos.p, d->chan.p, d->Q.p, d->hard.p, d->N, 1, 0, nullptr, nullptr, 0, 0};
-            const int waves = ((rc.count + d->link_rpw - 1) / d->link_rpw) * (nar == 1 ? V : nar == 2 ? V / 2 : 1);
+            LinkArgs lk{rc.link_col.p, rc.link_pos.p, d->chan.p, d->Q.p, d->hard.p, d->N, 1, 0, nullptr, nullptr, 0, 0,
+                        rc.n_big, rc.small_rows};
+            const int waves = link_chunk_count(d->link_rpw, rc.n_big, rc.small_rows, rc.count) * (nar == 1 ? V : nar == 2 ? V / 2 : 1);
             lk.link_blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
             err = hipEventRecord(ev[0], s);
-            (nar == 2 ? d->link_half_fn : nar == 1 ? d->link_narrow_fn : d->link_fn)[rc.degree]<<<dim3(lk.link_blocks, tiles), kBlock, 0, s>>>(a, lk);
+            (nar == 2 ? d->link_half_fn : nar == 1 ? d->link_narrow_fn : d->link_fn)[rc.degree]<<<dim3(tiles, lk.link_blocks), kBlock, 0, s>>>(a, lk);
             if (err == hipSuccess) err = hipEventRecord(ev[1], s);
             if (err == hipSuccess) err = hipEventSynchronize(ev[1]);
             float ms = 0;
@@ -1004,6 +1029,8 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     d->tune_link_narrow = ldpc::tune_pick(tune.link_half, false) ? 2 : (ldpc::tune_pick(tune.link_narrow, true) ? 1 : 0);
     d->tune_link_deep = ldpc::tune_pick(tune.link_deep, false);
     if (tune.link_rows) d->link_rpw = tune.link_rows < 0 ? 0 : tune.link_rows;
+    d->tune_link_guided = tune.link_guided;
+    HIP_TRY(hipDeviceGetAttribute(&d->cus, hipDeviceAttributeMultiprocessorCount, cfg->device));
     d->V = pick_frames_per_lane(*cfg, g->max_row_deg, g->max_col_deg);
     d->F = 64 * d->V;
     d->T = (cfg->max_batch + d->F - 1) / d->F;
