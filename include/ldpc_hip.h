@@ -139,8 +139,11 @@ enum ldpc_tune_field {
     LDPC_TUNE_MERGE = 20,       /* degree classes of one bucket share a launch (default on)         */
     LDPC_TUNE_LINK_DEEP = 22,   /* column-fused check kernel requests its inputs two rows ahead     */
     LDPC_TUNE_LINK_HALF = 24,   /* column-fused check kernel with 2 values per lane (tiles of 256)  */
-    LDPC_TUNE_LINK_GUIDED = 26  /* column-fused check kernel: its launch ends with shorter row chunks
+    LDPC_TUNE_LINK_GUIDED = 26, /* column-fused check kernel: its launch ends with shorter row chunks
                                    (default on from 4 tiles)                                         */
+    LDPC_TUNE_TILES_FIRST = 28  /* flooding launches as grids of (tiles, blocks): the blocks in flight
+                                   are spread over all tiles of the batch (default: the check-node
+                                   launches only; on: all; off: none)                               */
 };
 #define LDPC_TUNE_ON(field) (1 << (field))
 #define LDPC_TUNE_OFF(field) (2 << (field))

@@ -20,7 +20,7 @@ ALGOS = {"sp": ALGO_SP, "ms": ALGO_MS, "layered": ALGO_LAYERED, "ms_fused": ALGO
 # two-bit fields of ldpc_decoder_config.tune_flags (enum ldpc_tune_field): True forces on, False off
 TUNE_FIELDS = {"fused": 0, "ldsp": 2, "ldsp_ext": 4, "ldsp_pack": 6, "link_narrow": 8, "check_wide": 10,
                "syn_xcd": 12, "fused_pack": 14, "fused_loop": 16, "device_tail": 18, "merge": 20, "link_deep": 22, "link_half": 24,
-               "link_guided": 26}
+               "link_guided": 26, "tiles_first": 28}
 TUNE_INTS = ("rows_per_wave", "cols_per_wave", "link_rows", "compact", "ldsp_grid", "ldsp_per_cu", "ldsp_waves")
 
 
@@ -62,7 +62,7 @@ def tune_from_env(env=None):
     for name, key in (("FUSED", "fused"), ("LDSP", "ldsp"), ("LDSP_EXT", "ldsp_ext"), ("LDSP_PACK", "ldsp_pack"),
                       ("LINK_NARROW", "link_narrow"), ("CHECK_WIDE", "check_wide"), ("SYN_XCD", "syn_xcd"),
                       ("FUSED_LOOP", "fused_loop"), ("DEVICE_TAIL", "device_tail"), ("MERGE", "merge"), ("LINK_DEEP", "link_deep"), ("LINK_HALF", "link_half"),
-                      ("LINK_GUIDED", "link_guided")):
+                      ("LINK_GUIDED", "link_guided"), ("TILES_FIRST", "tiles_first")):
         if "LDPC_TUNE_" + name in env:
             t[key] = int(env["LDPC_TUNE_" + name]) != 0
     if "LDPC_TUNE_NO_PACK" in env:

@@ -189,7 +189,19 @@ struct CheckArgs {
     int32_t rows_per_wave;
     int32_t degree;                      /* generic kernel only */
     TailRef tail;
+    int32_t tiles_first = 0;             /* grid is (tiles, blocks) instead of (blocks, tiles): grid_pos() */
 };
+
+/* Where a block stands in the launch.  Blocks are dispatched with blockIdx.x varying fastest: a grid of
+ * (tiles, blocks) therefore has the blocks in flight at any moment spread over ALL tiles of the batch --
+ * sixteen regions 58 MB apart instead of one moving window -- which the memory system rewards (the
+ * column-fused check kernel: 1.39 -> 1.27 ms, profiles/r02_ab_tile_fastest_grid.txt).  The host asks for it
+ * whenever the block count fits gridDim.y. */
+struct GridPos { int row, block; };
+__device__ __forceinline__ GridPos grid_pos(int tiles_first)
+{
+    return tiles_first ? GridPos{(int)blockIdx.x, (int)blockIdx.y} : GridPos{(int)blockIdx.y, (int)blockIdx.x};
+}
 
 /* Sum-product, decodeCL.c:32-40: out_k = prod_{j != k} x_j, multiplied left to
  * right in ascending j starting from 1.0f (1*x is exact, so the chain starts at
@@ -255,9 +267,10 @@ __global__ __launch_bounds__(kBlock) void check_kernel(const CheckArgs a)
     constexpr size_t F = 64 * V;
     constexpr int SUB = V / W;
     const int lane = threadIdx.x & 63;
-    const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
+    const GridPos gp = grid_pos(a.tiles_first);
+    const int tile = tile_select<V>(a.tail, a.done, gp.row);
     if (tile < 0) return;
-    const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
+    const int wave = gp.block * kWavesPerBlock + wave_id_in_block();
     const int sub = wave % SUB;
     const int r_begin = (wave / SUB) * a.rows_per_wave;
     const int r_end = min(r_begin + a.rows_per_wave, a.n_rows);
@@ -340,9 +353,10 @@ __global__ __launch_bounds__(kBlock) void check_kernel_generic(const CheckArgs a
 {
     constexpr size_t F = 64 * V;
     const int lane = threadIdx.x & 63;
-    const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
+    const GridPos gp = grid_pos(a.tiles_first);
+    const int tile = tile_select<V>(a.tail, a.done, gp.row);
     if (tile < 0) return;
-    const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
+    const int wave = gp.block * kWavesPerBlock + wave_id_in_block();
     const int r_begin = wave * a.rows_per_wave;
     const int r_end = min(r_begin + a.rows_per_wave, a.n_rows);
     const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
@@ -400,11 +414,12 @@ __global__ __launch_bounds__(kBlock) void check_group_kernel(const CheckArgs a, 
 {
     constexpr size_t F = 64 * V;
     const int lane = threadIdx.x & 63;
-    const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
+    const GridPos gp = grid_pos(a.tiles_first);
+    const int tile = tile_select<V>(a.tail, a.done, gp.row);
     if (tile < 0) return;
     int c = 0;
-    while (c + 1 < n_classes && (int)blockIdx.x >= cls[c + 1].block_begin) ++c;
-    const int wave = ((int)blockIdx.x - cls[c].block_begin) * kWavesPerBlock + wave_id_in_block();
+    while (c + 1 < n_classes && gp.block >= cls[c + 1].block_begin) ++c;
+    const int wave = (gp.block - cls[c].block_begin) * kWavesPerBlock + wave_id_in_block();
     const int sub = wave % V;
     const int r_begin = (wave / V) * a.rows_per_wave;
     const int r_end = min(r_begin + a.rows_per_wave, cls[c].count);
@@ -505,6 +520,7 @@ struct VarArgs {
     int32_t write_q;                      /* 0 on the last round (MyLdpc.cpp:1035-1040) */
     int32_t degree;                       /* generic kernel only */
     TailRef tail;
+    int32_t tiles_first = 0;              /* grid is (tiles, blocks): grid_pos() */
 };
 
 /* Sum-product variable node: hardDecision (decodeCL.c:72-82) and refreshQ
@@ -569,9 +585,9 @@ struct LinkArgs {
     const int32_t *__restrict__ extra_e0;  /* [n_extra] first edge id */
     const int32_t *__restrict__ extra_deg; /* [n_extra] */
     int32_t n_extra;
-    int32_t link_blocks;                   /* blocks (gridDim.y) of the linked rows proper */
+    int32_t link_blocks;                   /* blocks of the linked rows proper */
     /* guided chunks: the first n_big row chunks of a tile hold rows_per_wave rows, the rest small_rows.
-     * The grid is (tiles, blocks): tiles vary fastest in dispatch order, so the launch ENDS with the short
+     * With a grid of (tiles, blocks) -- grid_pos() -- the launch ENDS with the short
      * chunks of all tiles and its last waves are short ones -- with equal chunks the CUs drain over a whole
      * chunk's time (16 rows: 176 us of a 1.39 ms launch, half of it lost). */
     int32_t n_big, small_rows;
@@ -596,11 +612,11 @@ __host__ __device__ inline int link_chunk_count(int rows_per_wave, int n_big, in
 
 /* the trailing blocks of a linked check launch: one left-over row per wave, V values per lane */
 template <int ALGO, int V, typename T>
-__device__ __forceinline__ void link_extra_rows(const CheckArgs &a, const LinkArgs &g, int tile)
+__device__ __forceinline__ void link_extra_rows(const CheckArgs &a, const LinkArgs &g, int tile, int block)
 {
     constexpr size_t F = 64 * V;
     const int lane = threadIdx.x & 63;
-    const int w = ((int)blockIdx.y - g.link_blocks) * kWavesPerBlock + wave_id_in_block();
+    const int w = (block - g.link_blocks) * kWavesPerBlock + wave_id_in_block();
     if (w >= g.n_extra) return;
     const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
     T *Rt = static_cast<T *>(a.R) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
@@ -618,10 +634,11 @@ __global__ __launch_bounds__(kBlock) LDPC_LINK_WIDE_ATTR void check_link_kernel(
 {
     constexpr size_t F = 64 * V;
     const int lane = threadIdx.x & 63;
-    const int tile = tile_select<V>(a.tail, a.done, blockIdx.x);
+    const GridPos gp = grid_pos(a.tiles_first);
+    const int tile = tile_select<V>(a.tail, a.done, gp.row);
     if (tile < 0) return;
-    if ((int)blockIdx.y >= g.link_blocks) { link_extra_rows<ALGO, V, T>(a, g, tile); return; }
-    const int wave = (int)blockIdx.y * kWavesPerBlock + wave_id_in_block();
+    if (gp.block >= g.link_blocks) { link_extra_rows<ALGO, V, T>(a, g, tile, gp.block); return; }
+    const int wave = gp.block * kWavesPerBlock + wave_id_in_block();
     int r_begin, r_end;
     link_chunk_rows(wave, a.rows_per_wave, g.n_big, g.small_rows, a.n_rows, &r_begin, &r_end);
     const size_t lane_off = (size_t)lane * V;
@@ -764,10 +781,11 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow_kernel(const CheckAr
     constexpr int SUBS = V / W;                      /* sub-waves per row chunk */
     constexpr int FB = 64 / SUBS;                    /* bits per field */
     const int lane = threadIdx.x & 63;
-    const int tile = tile_select<V>(a.tail, a.done, blockIdx.x);
+    const GridPos gp = grid_pos(a.tiles_first);
+    const int tile = tile_select<V>(a.tail, a.done, gp.row);
     if (tile < 0) return;
-    if ((int)blockIdx.y >= g.link_blocks) { link_extra_rows<ALGO, V, T>(a, g, tile); return; }
-    const int wave = (int)blockIdx.y * kWavesPerBlock + wave_id_in_block();
+    if (gp.block >= g.link_blocks) { link_extra_rows<ALGO, V, T>(a, g, tile, gp.block); return; }
+    const int wave = gp.block * kWavesPerBlock + wave_id_in_block();
     const int sub = wave % SUBS;
     int r_begin, r_end;
     link_chunk_rows(wave / SUBS, a.rows_per_wave, g.n_big, g.small_rows, a.n_rows, &r_begin, &r_end);
@@ -899,10 +917,11 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow2_kernel(const CheckA
     constexpr size_t F = 64 * V;
     constexpr int FB = 64 / V;                       /* bits per field */
     const int lane = threadIdx.x & 63;
-    const int tile = tile_select<V>(a.tail, a.done, blockIdx.x);
+    const GridPos gp = grid_pos(a.tiles_first);
+    const int tile = tile_select<V>(a.tail, a.done, gp.row);
     if (tile < 0) return;
-    if ((int)blockIdx.y >= g.link_blocks) { link_extra_rows<ALGO, V, T>(a, g, tile); return; }
-    const int wave = (int)blockIdx.y * kWavesPerBlock + wave_id_in_block();
+    if (gp.block >= g.link_blocks) { link_extra_rows<ALGO, V, T>(a, g, tile, gp.block); return; }
+    const int wave = gp.block * kWavesPerBlock + wave_id_in_block();
     const int sub = wave % V;
     int r_begin, r_end;
     link_chunk_rows(wave / V, a.rows_per_wave, g.n_big, g.small_rows, a.n_rows, &r_begin, &r_end);
@@ -1080,9 +1099,10 @@ __global__ __launch_bounds__(kBlock) LDPC_VAR_ATTR void var_kernel(const VarArgs
 {
     constexpr size_t F = 64 * V;
     const int lane = threadIdx.x & 63;
-    const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
+    const GridPos gp = grid_pos(a.tiles_first);
+    const int tile = tile_select<V>(a.tail, a.done, gp.row);
     if (tile < 0) return;
-    const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
+    const int wave = gp.block * kWavesPerBlock + wave_id_in_block();
     const int c_begin = wave * a.cols_per_wave;
     const int c_end = min(c_begin + a.cols_per_wave, a.n_cols);
     const T *Rt = static_cast<const T *>(a.R) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
@@ -1119,11 +1139,12 @@ __global__ __launch_bounds__(kBlock) void var_group_kernel(const VarArgs a, cons
 {
     constexpr size_t F = 64 * V;
     const int lane = threadIdx.x & 63;
-    const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
+    const GridPos gp = grid_pos(a.tiles_first);
+    const int tile = tile_select<V>(a.tail, a.done, gp.row);
     if (tile < 0) return;
     int c = 0;
-    while (c + 1 < n_classes && (int)blockIdx.x >= cls[c + 1].block_begin) ++c;
-    const int wave = ((int)blockIdx.x - cls[c].block_begin) * kWavesPerBlock + wave_id_in_block();
+    while (c + 1 < n_classes && gp.block >= cls[c + 1].block_begin) ++c;
+    const int wave = (gp.block - cls[c].block_begin) * kWavesPerBlock + wave_id_in_block();
     const int c_begin = wave * a.cols_per_wave;
     const int c_end = min(c_begin + a.cols_per_wave, cls[c].count);
     const T *Rt = static_cast<const T *>(a.R) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
@@ -1142,9 +1163,10 @@ __global__ __launch_bounds__(kBlock) void var_kernel_generic(const VarArgs a)
 {
     constexpr size_t F = 64 * V;
     const int lane = threadIdx.x & 63;
-    const int tile = tile_select<V>(a.tail, a.done, blockIdx.y);
+    const GridPos gp = grid_pos(a.tiles_first);
+    const int tile = tile_select<V>(a.tail, a.done, gp.row);
     if (tile < 0) return;
-    const int wave = (int)blockIdx.x * kWavesPerBlock + wave_id_in_block();
+    const int wave = gp.block * kWavesPerBlock + wave_id_in_block();
     const int c_begin = wave * a.cols_per_wave;
     const int c_end = min(c_begin + a.cols_per_wave, a.n_cols);
     const int D = a.degree;

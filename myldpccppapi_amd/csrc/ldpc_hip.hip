@@ -210,6 +210,7 @@ struct ldpc_decoder {
     float link_cal_ms[3] = {0, 0, 0};   /* what the calibration measured per launch: [0] wide, [1] narrow, [2] half */
     int link_rpw = 16;                  /* rows per wave of the fused check kernel; 0 = fusion off */
     int tune_link_guided = 0;           /* tri-state: shorter row chunks at the end of the fused check launch */
+    int tune_tiles_first = 0;           /* tri-state: flooding launches as (tiles, blocks) grids (flood_grid) */
     int cus = 256;                      /* compute units of the device */
     VarFn var_fn[ldpc::kMaxUnrolledDegree + 1] = {};
 
@@ -367,6 +368,16 @@ hipError_t span_end(ldpc_decoder *d, hipStream_t s)
     return hipEventRecord(d->spans[d->spans_used++].b, s);
 }
 
+/* grid of a flooding launch: (tiles, blocks) -- flood_kernels.hpp: grid_pos() -- when the blocks fit gridDim.y */
+static inline dim3 flood_grid(const ldpc_decoder *d, unsigned blocks, unsigned tiles, int32_t *tiles_first, bool check_node = false)
+{
+    /* tune_tiles_first: 0 automatic = the check-node launches only (contiguous rows: +8 % there; the
+     * variable-node launches gather anyway and lose 4 %), 1 all, 2 none */
+    const bool want = d->tune_tiles_first == 1 || (d->tune_tiles_first == 0 && check_node);
+    *tiles_first = (blocks <= 65535u && want) ? 1 : 0;
+    return *tiles_first ? dim3(tiles, blocks) : dim3(blocks, tiles);
+}
+
 template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t frames,
                                   uint8_t *out_dev, int64_t out_bytes, int32_t *iters_dev,
                                   hipStream_t s, int start_round = 1);
@@ -477,7 +488,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             const int waves = link_chunk_count(d->link_rpw, rc.n_big, rc.small_rows, rc.count) * (variant == 1 ? V : variant == 2 ? V / 2 : 1);
             lk.link_blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
             /* tiles vary fastest: the short chunks of all tiles are the launch's last blocks */
-            dim3 grid(tiles, lk.link_blocks + (d->n_extra + kWavesPerBlock - 1) / kWavesPerBlock);
+            const dim3 grid = flood_grid(d, lk.link_blocks + (d->n_extra + kWavesPerBlock - 1) / kWavesPerBlock, tiles, &a.tiles_first, true);
             (variant == 2 ? d->link_half_fn : variant == 1 ? (d->tune_link_deep ? d->link_deep_fn : d->link_narrow_fn) : d->link_fn)
                 [rc.degree]<<<grid, kBlock, 0, s>>>(a, lk);
             HIP_TRY(span_end(d, s));
@@ -487,8 +498,8 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             for (int i : g.members) edges += (int64_t)d->row_classes[i].degree * d->row_classes[i].count;
             HIP_TRY(span_begin(d, s, 5, g.hi, 2 * msz * edges * frames, -1, g.lo));
             CheckArgs a{d->Q.p, d->R.p, nullptr, d->done.p, d->E, 0, (d->tune_rpw ? d->tune_rpw : 2) * (fat ? kIdleFat : 1), 0, tr};
-            d->check_group_fn[g.bucket]<<<dim3(fat ? g.blocks_fat : g.blocks, tiles), kBlock, 0, s>>>(
-                a, fat ? g.table_fat.p : g.table.p, (int)g.members.size());
+            const dim3 grid = flood_grid(d, fat ? g.blocks_fat : g.blocks, tiles, &a.tiles_first, true);
+            d->check_group_fn[g.bucket]<<<grid, kBlock, 0, s>>>(a, fat ? g.table_fat.p : g.table.p, (int)g.members.size());
             HIP_TRY(span_end(d, s));
         }
         for (int ci : d->check_solo) {
@@ -500,7 +511,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             const int rpw = (d->tune_rpw ? d->tune_rpw : (narrow ? 2 : 1)) * (fat ? kIdleFat : 1);
             a.rows_per_wave = rpw;
             const int waves = ((rc.count + rpw - 1) / rpw) * (narrow ? V : 1);
-            dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
+            const dim3 grid = flood_grid(d, (waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles, &a.tiles_first, true);
             (narrow ? d->check_fn : d->check_fn_wide)[slotk]<<<grid, kBlock, 0, s>>>(a);
             HIP_TRY(span_end(d, s));
         }
@@ -512,8 +523,8 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             HIP_TRY(span_begin(d, s, 6, g.hi, msz * units * frames, -1, g.lo));
             VarArgs a{d->R.p, d->Q.p, d->chan.p, d->hard.p, d->done.p, nullptr, nullptr,
                       d->E, d->N, 0, (d->tune_cpw ? d->tune_cpw : 1) * (fat ? kIdleFat : 1), wq, 0, tr};
-            d->var_group_fn[g.bucket]<<<dim3(fat ? g.blocks_fat : g.blocks, tiles), kBlock, 0, s>>>(
-                a, fat ? g.table_fat.p : g.table.p, (int)g.members.size());
+            const dim3 grid = flood_grid(d, fat ? g.blocks_fat : g.blocks, tiles, &a.tiles_first);
+            d->var_group_fn[g.bucket]<<<grid, kBlock, 0, s>>>(a, fat ? g.table_fat.p : g.table.p, (int)g.members.size());
             HIP_TRY(span_end(d, s));
         }
         for (int ci : d->var_solo) {
@@ -525,7 +536,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             a.cols_per_wave = cpw;
             const int slotk = cc.degree <= kMaxUnrolledDegree ? cc.degree : 0;
             const int waves = (cc.count + cpw - 1) / cpw;
-            dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
+            const dim3 grid = flood_grid(d, (waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles, &a.tiles_first);
             d->var_fn[slotk]<<<grid, kBlock, 0, s>>>(a);
             HIP_TRY(span_end(d, s));
         }
@@ -825,8 +836,9 @@ template <int V> int calibrate_link(ldpc_decoder *d)
                         rc.n_big, rc.small_rows};
             const int waves = link_chunk_count(d->link_rpw, rc.n_big, rc.small_rows, rc.count) * (nar == 1 ? V : nar == 2 ? V / 2 : 1);
             lk.link_blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+            const dim3 grid = flood_grid(d, lk.link_blocks, tiles, &a.tiles_first, true);
             err = hipEventRecord(ev[0], s);
-            (nar == 2 ? d->link_half_fn : nar == 1 ? d->link_narrow_fn : d->link_fn)[rc.degree]<<<dim3(tiles, lk.link_blocks), kBlock, 0, s>>>(a, lk);
+            (nar == 2 ? d->link_half_fn : nar == 1 ? d->link_narrow_fn : d->link_fn)[rc.degree]<<<grid, kBlock, 0, s>>>(a, lk);
             if (err == hipSuccess) err = hipEventRecord(ev[1], s);
             if (err == hipSuccess) err = hipEventSynchronize(ev[1]);
             float ms = 0;
@@ -1030,6 +1042,7 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     d->tune_link_deep = ldpc::tune_pick(tune.link_deep, false);
     if (tune.link_rows) d->link_rpw = tune.link_rows < 0 ? 0 : tune.link_rows;
     d->tune_link_guided = tune.link_guided;
+    d->tune_tiles_first = tune.tiles_first;
     HIP_TRY(hipDeviceGetAttribute(&d->cus, hipDeviceAttributeMultiprocessorCount, cfg->device));
     d->V = pick_frames_per_lane(*cfg, g->max_row_deg, g->max_col_deg);
     d->F = 64 * d->V;

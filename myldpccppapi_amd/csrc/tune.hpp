@@ -12,7 +12,7 @@ namespace ldpc {
 struct Tune {
     /* tri-state: 0 automatic, 1 forced on, 2 forced off */
     int fused = 0, ldsp = 0, ldsp_ext = 0, ldsp_pack = 0, link_narrow = 0, check_wide = 0, syn_xcd = 0,
-        fused_pack = 0, fused_loop = 0, device_tail = 0, merge = 0, link_deep = 0, link_half = 0, link_guided = 0;
+        fused_pack = 0, fused_loop = 0, device_tail = 0, merge = 0, link_deep = 0, link_half = 0, link_guided = 0, tiles_first = 0;
     int rows_per_wave = 0, cols_per_wave = 0;
     int link_rows = 0;          /* 0 automatic, -1 fusion off */
     int compact = 0;            /* 0 automatic, -1 off */
@@ -37,6 +37,7 @@ inline Tune tune_from_config(const ldpc_decoder_config &c)
     t.link_deep = f(LDPC_TUNE_LINK_DEEP);
     t.link_half = f(LDPC_TUNE_LINK_HALF);
     t.link_guided = f(LDPC_TUNE_LINK_GUIDED);
+    t.tiles_first = f(LDPC_TUNE_TILES_FIRST);
     t.rows_per_wave = c.tune_rows_per_wave;
     t.cols_per_wave = c.tune_cols_per_wave;
     t.link_rows = c.tune_link_rows;
@@ -55,9 +56,9 @@ inline bool tune_forced_off(int tri) { return tri == 2; }
 /* field 3 (both bits) is not a value */
 inline bool tune_valid(const ldpc_decoder_config &c)
 {
-    for (int field = 0; field <= LDPC_TUNE_LINK_GUIDED; field += 2)
+    for (int field = 0; field <= LDPC_TUNE_TILES_FIRST; field += 2)
         if (((c.tune_flags >> field) & 3) == 3) return false;
-    if (c.tune_flags >> (LDPC_TUNE_LINK_GUIDED + 2)) return false;
+    if (c.tune_flags >> (LDPC_TUNE_TILES_FIRST + 2)) return false;
     return c.tune_rows_per_wave >= 0 && c.tune_rows_per_wave <= 4096 && c.tune_cols_per_wave >= 0 &&
            c.tune_cols_per_wave <= 4096 && c.tune_link_rows >= -1 && c.tune_link_rows <= 4096 &&
            c.tune_compact >= -1 && c.tune_ldsp_grid >= 0 && c.tune_ldsp_shape >= 0 && c.tune_ldsp_shape < 65536 &&

@@ -122,7 +122,7 @@ def test_tuning_fields_are_validated_and_no_environment_is_read(built):
     rows, cols = codes.wimax_edges(codes.RATE_1_2, 648)
     g = L.Graph(rows, cols, 324, 648)
     lib = _lib.load()
-    for field, value in (("tune_flags", 3), ("tune_flags", 1 << 28), ("tune_rows_per_wave", -1), ("tune_link_rows", -2),
+    for field, value in (("tune_flags", 3), ("tune_flags", 1 << 30), ("tune_rows_per_wave", -1), ("tune_link_rows", -2),
                          ("tune_compact", -2), ("tune_ldsp_shape", 1 << 16), ("streams", 9), ("streams", -1)):
         cfg = _lib.DecoderConfig()
         lib.ldpc_decoder_config_init(ctypes.byref(cfg))
