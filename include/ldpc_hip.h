@@ -142,8 +142,8 @@ enum ldpc_tune_field {
     LDPC_TUNE_LINK_GUIDED = 26, /* column-fused check kernel: its launch ends with shorter row chunks
                                    (default on from 4 tiles)                                         */
     LDPC_TUNE_TILES_FIRST = 28  /* flooding launches as grids of (tiles, blocks): the blocks in flight
-                                   are spread over all tiles of the batch (default: the check-node
-                                   launches only; on: all; off: none)                               */
+                                   are spread over all tiles of the batch (default: the column-fused
+                                   check launch only; on: all; off: none)                               */
 };
 #define LDPC_TUNE_ON(field) (1 << (field))
 #define LDPC_TUNE_OFF(field) (2 << (field))

@@ -369,11 +369,12 @@ hipError_t span_end(ldpc_decoder *d, hipStream_t s)
 }
 
 /* grid of a flooding launch: (tiles, blocks) -- flood_kernels.hpp: grid_pos() -- when the blocks fit gridDim.y */
-static inline dim3 flood_grid(const ldpc_decoder *d, unsigned blocks, unsigned tiles, int32_t *tiles_first, bool check_node = false)
+static inline dim3 flood_grid(const ldpc_decoder *d, unsigned blocks, unsigned tiles, int32_t *tiles_first, bool linked = false)
 {
-    /* tune_tiles_first: 0 automatic = the check-node launches only (contiguous rows: +8 % there; the
-     * variable-node launches gather anyway and lose 4 %), 1 all, 2 none */
-    const bool want = d->tune_tiles_first == 1 || (d->tune_tiles_first == 0 && check_node);
+    /* tune_tiles_first: 0 automatic = the column-fused check launch only (-8 % there; the variable-node
+     * launches gather anyway and lose 4 %, the plain check launches of the rate-9/10 code 1.7 %), 1 all,
+     * 2 none */
+    const bool want = d->tune_tiles_first == 1 || (d->tune_tiles_first == 0 && linked);
     *tiles_first = (blocks <= 65535u && want) ? 1 : 0;
     return *tiles_first ? dim3(tiles, blocks) : dim3(blocks, tiles);
 }
@@ -498,7 +499,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             for (int i : g.members) edges += (int64_t)d->row_classes[i].degree * d->row_classes[i].count;
             HIP_TRY(span_begin(d, s, 5, g.hi, 2 * msz * edges * frames, -1, g.lo));
             CheckArgs a{d->Q.p, d->R.p, nullptr, d->done.p, d->E, 0, (d->tune_rpw ? d->tune_rpw : 2) * (fat ? kIdleFat : 1), 0, tr};
-            const dim3 grid = flood_grid(d, fat ? g.blocks_fat : g.blocks, tiles, &a.tiles_first, true);
+            const dim3 grid = flood_grid(d, fat ? g.blocks_fat : g.blocks, tiles, &a.tiles_first);
             d->check_group_fn[g.bucket]<<<grid, kBlock, 0, s>>>(a, fat ? g.table_fat.p : g.table.p, (int)g.members.size());
             HIP_TRY(span_end(d, s));
         }
@@ -511,7 +512,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             const int rpw = (d->tune_rpw ? d->tune_rpw : (narrow ? 2 : 1)) * (fat ? kIdleFat : 1);
             a.rows_per_wave = rpw;
             const int waves = ((rc.count + rpw - 1) / rpw) * (narrow ? V : 1);
-            const dim3 grid = flood_grid(d, (waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles, &a.tiles_first, true);
+            const dim3 grid = flood_grid(d, (waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles, &a.tiles_first);
             (narrow ? d->check_fn : d->check_fn_wide)[slotk]<<<grid, kBlock, 0, s>>>(a);
             HIP_TRY(span_end(d, s));
         }
