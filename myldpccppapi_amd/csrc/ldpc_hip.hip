@@ -640,9 +640,11 @@ int build_classes(ldpc_decoder *d, const ldpc_graph *g)
             rc.n_big = (rc.count + rpw - 1) / rpw;
             rc.small_rows = rpw;
             const int small = std::max(2, rpw / 4);
-            if (d->T >= 4 && small < rpw && !ldpc::tune_forced_off(d->tune_link_guided)) {
+            const bool forced = ldpc::tune_forced_on(d->tune_link_guided);         /* tests: also on small launches */
+            if ((d->T >= 4 || forced) && small < rpw && !ldpc::tune_forced_off(d->tune_link_guided)) {
                 const int64_t last_generation = (int64_t)d->cus * 16 / d->T;       /* chunks per tile */
-                const int64_t big = (int64_t)rc.n_big - last_generation;
+                int64_t big = (int64_t)rc.n_big - last_generation;
+                if (big <= 0 && forced) big = rc.n_big - std::max(1, rc.n_big / 3);
                 if (big > 0) { rc.n_big = (int)big; rc.small_rows = small; }
             }
             std::vector<char> chunk_end((size_t)rc.count, 0);

@@ -355,7 +355,11 @@ def test_column_local_fusion_on_staircase_code(built, algo):
     y = channel.awgn_frames(N2, 0, 70, 0.72 if algo == "ms" else 0.8, seed=14)
     want = oracle.decode(og, y, algo, max_iter=25, tap_iter=2)
     for rpw, variant in ((8, {}), (3, {}), (-1, {}), (16, {"link_deep": True}), (7, {"link_deep": True}), (2, {"link_deep": True}),
-                         (8, {"link_narrow": False}), (5, {"link_half": True}), (16, {"link_half": True})):
+                         (8, {"link_narrow": False}), (5, {"link_half": True}), (16, {"link_half": True}),
+                         # guided row chunks (the launch ends with chunks of a quarter of the rows), every kernel form
+                         (16, {"link_guided": True}), (9, {"link_guided": True, "link_narrow": False}),
+                         (16, {"link_guided": True, "link_half": True}), (12, {"link_guided": True, "link_deep": True}),
+                         (16, {"link_guided": True, "tiles_first": False}), (8, {"tiles_first": True})):
         for V in (1, 4):
             # link_deep: inputs requested two rows ahead; link_narrow False: V values per lane; link_half: 2 per lane (V = 4)
             dec = L.Decoder(g, K2, max_batch=70, algo=algo, max_iter=25, frames_per_lane=V,
