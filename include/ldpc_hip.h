@@ -277,6 +277,9 @@ int ldpc_count_errors_device(const uint8_t *out_dev, const uint8_t *ref_dev, int
  *      {default, non-temporal}.  The benchmark reports it next to its roofline figures so that a kernel's fraction of
  *      the 8 TB/s specification can also be read against what the box at hand delivers. */
 int ldpc_hbm_probe_device(int32_t device, int64_t bytes, int32_t reps, double *copy_gbs, double *by_policy);
+/* The non-temporal copy back to back for `milliseconds` (the first third untimed): the rate the box SUSTAINS.
+ * The boxes of this pool drop to about 5.2 TB/s under load at times while a burst still shows 6.4. */
+int ldpc_hbm_sustained_device(int32_t device, int64_t bytes, int32_t milliseconds, double *copy_gbs);
 
 #ifdef __cplusplus
 }

@@ -58,7 +58,7 @@ EXPORTS = (
     "ldpc_graph_destroy", "ldpc_graph_info", "ldpc_decoder_config_init", "ldpc_decoder_create",
     "ldpc_decoder_create_multi", "ldpc_shard_range", "ldpc_decoder_destroy", "ldpc_decode", "ldpc_decode_device", "ldpc_out_bytes",
     "ldpc_decoder_set_timing", "ldpc_decoder_stats", "ldpc_decoder_kernel_times", "ldpc_decoder_set_tap",
-    "ldpc_decoder_dump", "ldpc_awgn_device", "ldpc_count_errors_device", "ldpc_hbm_probe_device",
+    "ldpc_decoder_dump", "ldpc_awgn_device", "ldpc_count_errors_device", "ldpc_hbm_probe_device", "ldpc_hbm_sustained_device",
 )
 
 
@@ -108,6 +108,7 @@ def load():
     L.ldpc_awgn_device.argtypes = [vp, ctypes.c_int64, ctypes.c_int32, vp, ctypes.c_float, ctypes.c_uint64,
                                    ctypes.c_int64, ctypes.c_int32, vp]
     L.ldpc_count_errors_device.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, i64p, ctypes.c_int32, vp]
+    L.ldpc_hbm_sustained_device.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
     L.ldpc_hbm_probe_device.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32,
                                         ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     _lib = L

@@ -53,6 +53,13 @@ def hbm_probe(device=0, nbytes=1 << 30, reps=5, by_policy=False):
     return (g.value, two[0], two[1]) if by_policy else g.value
 
 
+def hbm_sustained(device=0, nbytes=1 << 30, milliseconds=300):
+    """GB/s of the non-temporal float4 copy run back to back for `milliseconds` (first third untimed)."""
+    g = ctypes.c_double(0.0)
+    _lib.check(_lib.load().ldpc_hbm_sustained_device(int(device), int(nbytes), int(milliseconds), ctypes.byref(g)))
+    return g.value
+
+
 def tune_from_env(env=None):
     """For the measurement scripts under tools/: translate LDPC_TUNE_* environment switches into
     a tuning dict for Decoder(tune=...).  The library itself reads no environment variables."""

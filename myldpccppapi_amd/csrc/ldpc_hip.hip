@@ -1965,4 +1965,58 @@ int ldpc_hbm_probe_device(int32_t device, int64_t bytes, int32_t reps, double *c
     return LDPC_OK;
 }
 
+/* The same non-temporal copy, back to back for `milliseconds`: what the box sustains (its memory throttles
+ * under load at times: a burst of a few launches does not see that). */
+int ldpc_hbm_sustained_device(int32_t device, int64_t bytes, int32_t milliseconds, double *copy_gbs)
+{
+    if (!copy_gbs) return fail(LDPC_ERR_ARG, "copy_gbs is NULL");
+    *copy_gbs = 0.0;
+    if (bytes < (1 << 20) || bytes > ((int64_t)16 << 30) || milliseconds < 1 || milliseconds > 10000)
+        return fail(LDPC_ERR_ARG, "sustained probe: bytes in [1 MiB, 16 GiB], milliseconds in [1, 10000]");
+    HIP_TRY(hipSetDevice(device));
+    const size_t n4 = (size_t)bytes / sizeof(ldpc::vf4);
+    ldpc::vf4 *src = nullptr, *dst = nullptr;
+    hipStream_t s = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t e = hipMalloc((void **)&src, n4 * sizeof(ldpc::vf4));
+    if (e == hipSuccess) e = hipMalloc((void **)&dst, n4 * sizeof(ldpc::vf4));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&a);
+    if (e == hipSuccess) e = hipEventCreate(&b);
+    if (e == hipSuccess) e = hipMemsetAsync(src, 0x3c, n4 * sizeof(ldpc::vf4), s);
+    const unsigned grid = (unsigned)std::min<size_t>((n4 + 1023) / 1024, 256 * 64);
+    /* one launch's time from a short burst, then a third of the time untimed and two thirds timed */
+    float one_ms = 0.0f;
+    if (e == hipSuccess) {
+        hbm_probe_copy_kernel<true><<<grid, 256, 0, s>>>(src, dst, n4);
+        e = hipEventRecord(a, s);
+        for (int r = 0; r < 4; ++r) hbm_probe_copy_kernel<true><<<grid, 256, 0, s>>>(src, dst, n4);
+        if (e == hipSuccess) e = hipEventRecord(b, s);
+        if (e == hipSuccess) e = hipEventSynchronize(b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&one_ms, a, b);
+        one_ms /= 4.0f;
+    }
+    int timed = 0;
+    float ms = 0.0f;
+    if (e == hipSuccess && one_ms > 0.0f) {
+        const int total = std::max(6, std::min(200000, (int)((float)milliseconds / one_ms)));
+        const int lead = total / 3;
+        timed = total - lead;
+        for (int r = 0; r < lead; ++r) hbm_probe_copy_kernel<true><<<grid, 256, 0, s>>>(src, dst, n4);
+        e = hipEventRecord(a, s);
+        for (int r = 0; r < timed; ++r) hbm_probe_copy_kernel<true><<<grid, 256, 0, s>>>(src, dst, n4);
+        if (e == hipSuccess) e = hipEventRecord(b, s);
+        if (e == hipSuccess) e = hipEventSynchronize(b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    }
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    if (s) (void)hipStreamDestroy(s);
+    if (src) (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+    if (e != hipSuccess) return fail(LDPC_ERR_HIP, "hbm sustained probe: %s", hipGetErrorString(e));
+    if (ms > 0.0f) *copy_gbs = 2.0 * (double)(n4 * sizeof(ldpc::vf4)) * timed / (ms * 1e-3) / 1e9;
+    return LDPC_OK;
+}
+
 }  /* extern "C" */
