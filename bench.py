@@ -170,8 +170,8 @@ def host_path(g, groups=3, B=BATCH_PER_GPU):
 def streams_overlap(g, B, steps, warmup, algo, device=0):
     """The headline workload with the batch cut into 2 and 4 frame ranges on streams of their own
     (ldpc_decoder_config.streams): one range's kernels fill the GPU while another's kernel drains.  Same
-    frames, same bytes (checked against the single-stream output); reported beside the headline, whose
-    per-launch durations are only meaningful for kernels that run alone."""
+    frames, same bytes (checked against the single-stream output); reported beside the headline: the step has
+    two regimes (about 123 and 137 ms) and which cut of the batch gets which varies by box."""
     import torch
     import myldpccppapi_amd as L
     from myldpccppapi_amd import channel
@@ -319,7 +319,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the config's)")
-    ap.add_argument("--config", default="dvbs2_sp", choices=["dvbs2_sp"] + sorted(EXTRA_CONFIGS),
+    ap.add_argument("--config", default="dvbs2_sp", choices=["dvbs2_sp", "streams_probe"] + sorted(EXTRA_CONFIGS),
                     help="dvbs2_sp = the headline workload (default); others are extra measurement points")
     ap.add_argument("--algo", default="sp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -356,6 +356,13 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    if args.config == "streams_probe":      # the `streams` block of the headline line, in a process of its own
+        import myldpccppapi_amd as L
+        from myldpccppapi_amd import codes
+        rows, cols = codes.dvbs2_profile_edges(N_CODE, K_CODE)
+        g = L.Graph(rows, cols, N_CODE - K_CODE, N_CODE)
+        print(json.dumps(streams_overlap(g, args.batch or BATCH_PER_GPU, args.steps, args.warmup, args.algo, local_rank)), flush=True)
+        return
     if args.config != "dvbs2_sp":
         if world > 1:
             sys.exit("extra configs are single-GPU measurements")
@@ -422,6 +429,9 @@ def main():
     st = dec.stats()
     kt = dec.kernel_times()
     assert st["iterations_launched"] == ITERS
+    # frames one launch works on: the whole batch, or one stream's range (the kernel times are the first range's)
+    streams_on = args.streams > 1 and B >= 512 * args.streams and K_CODE % 8 == 0
+    launch_frames = ((B + args.streams - 1) // args.streams + 255) // 256 * 256 if streams_on else B
     if rank == 0:
         frames_total = B * world * args.steps
         value = frames_total * K_CODE / dt / 1e6
@@ -445,10 +455,10 @@ def main():
                 tc = tj.get("__config__", {})
                 per = tj.get(dom["name"])
                 if per is not None and tc.get("frames_per_gpu"):
-                    traffic = int(per * B / tc["frames_per_gpu"])         # linear in the frames of a launch
+                    traffic = int(per * launch_frames / tc["frames_per_gpu"])         # linear in the frames of a launch
                     traffic_note = ("PMC FETCH_SIZE x2 + WRITE_SIZE per launch from %s (rocprofv3, separate passes, "
                                     "%d frames per launch%s)" % (tc.get("source", "profiles/"), tc["frames_per_gpu"],
-                                                                 "" if tc["frames_per_gpu"] == B else ", scaled to %d" % B))
+                                                                 "" if tc["frames_per_gpu"] == launch_frames else ", scaled to %d" % launch_frames))
             except Exception:
                 traffic = None
         probe = None
@@ -475,6 +485,7 @@ def main():
                             "(probability domain), all-zero codeword + AWGN sigma=%.2f (no frame converges), "
                             "early termination on, inputs resident in HBM" % (B, ITERS, SIGMA),
                 "global_batch": B * world, "frames_per_gpu": B, "iterations": ITERS, "algo": args.algo,
+                "streams": args.streams if streams_on else 1, "frames_per_launch": launch_frames,
                 "parallelism": "frames sharded over %d GPU(s), all-gather of decoded bytes" % world,
                 "coded_mbit_s": round(value * N_CODE / K_CODE, 2),
                 "frames_converged": st["frames_converged"],
@@ -512,7 +523,7 @@ def main():
                     "algorithmic_achieved": round(all_bytes / (all_ms * 1e-3) / 1e9, 1),
                     "algorithmic_frac": round(all_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "bytes_per_frame_iteration": 16 * g.E + 4 * N_CODE,
-                    "moved_bytes_per_frame_iteration": int(all_moved / (dom["launches"] * B)),
+                    "moved_bytes_per_frame_iteration": int(all_moved / (dom["launches"] * launch_frames)),
                     "per_kernel": {k["name"]: {"avg_ms": round(k["ms_total"] / k["launches"], 4),
                                                "GB/s": round(k["bytes_moved"] / (k["ms_total"] * 1e-3) / 1e9, 1)}
                                    for k in flood},
@@ -541,8 +552,14 @@ def main():
                 except Exception as e:      # an extra point must never cost the headline line
                     extra[key] = {"error": repr(e)}
             res["extra"] = extra
+            # in a process of its own: nothing that happens there can cost the headline line
             try:
-                res["streams"] = streams_overlap(g, B, max(3, args.steps // 2), 1, args.algo, local_rank)
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "streams_probe", "--batch", str(B),
+                                    "--steps", str(max(3, args.steps // 2)), "--warmup", "1", "--algo", args.algo],
+                                   capture_output=True, text=True, timeout=300,
+                                   env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+                line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+                res["streams"] = json.loads(line[-1]) if p.returncode == 0 and line else {"error": "rc %d: %s" % (p.returncode, p.stderr[-300:])}
             except Exception as e:
                 res["streams"] = {"error": repr(e)}
             try:

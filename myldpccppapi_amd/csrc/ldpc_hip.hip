@@ -1284,10 +1284,20 @@ static int decode_device_streams(ldpc_decoder *d, const float *llr_dev, int64_t 
     }
     std::vector<int> rcs((size_t)n, LDPC_OK);
     std::vector<std::string> errs((size_t)n);
+    /* A call whose launches are timed (ldpc_decoder_set_timing) runs its ranges ONE AFTER THE OTHER: a
+     * launch's duration is a bandwidth figure only while the launch has the GPU to itself.  (Every
+     * sub-decoder counts its calls the same way, so the first one tells.) */
+    const bool blocking = d->cfg.poll_interval > 0 && d->cfg.early_term;
+    const ldpc_decoder *first = d->shards[0];
+    const bool timed_call = first->timing_every > 0 && (first->timing_calls % first->timing_every) == 0;
     auto work = [&](int i) {
         ldpc_decoder *sh = d->shards[i];
         if (hi[i] <= lo[i]) return;
-        if (hipSetDevice(d->cfg.device) != hipSuccess || hipStreamWaitEvent(sh->stream, d->ev_in, 0) != hipSuccess) {
+        hipError_t we = hipSetDevice(d->cfg.device);
+        if (we == hipSuccess) we = hipStreamWaitEvent(sh->stream, d->ev_in, 0);
+        if (we == hipSuccess && timed_call && i > 0 && d->shards[i - 1]->have_last)
+            we = hipStreamWaitEvent(sh->stream, d->shards[i - 1]->ev_end, 0);
+        if (we != hipSuccess) {
             rcs[i] = fail(LDPC_ERR_HIP, "stream %d: cannot wait for the caller's stream", i);
             errs[i] = g_err;
             return;
@@ -1301,10 +1311,9 @@ static int decode_device_streams(ldpc_decoder *d, const float *llr_dev, int64_t 
     };
     std::vector<std::thread> threads;
     std::vector<int> inline_work;
-    const bool blocking = d->cfg.poll_interval > 0 && d->cfg.early_term;
     for (int i = 1; i < n; ++i) {
         if (hi[i] <= lo[i]) continue;
-        if (!blocking) { inline_work.push_back(i); continue; }
+        if (!blocking || timed_call) { inline_work.push_back(i); continue; }     /* timed: in order, on this thread */
         try { threads.emplace_back(work, i); }
         catch (...) { inline_work.push_back(i); }
     }
