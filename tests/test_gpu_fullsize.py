@@ -396,3 +396,6 @@ def test_hbm_probe_reports_both_cache_policies(built):
     assert 1000.0 < plain < 8000.0 and 1000.0 < nt < 8000.0, (plain, nt)
     with pytest.raises(L.LdpcError):
         L.capi.hbm_probe(0, 1 << 10, 3)                                     # below 1 MiB: refused
+    # the same copy back to back for 50 ms: a plausible rate too, not above the burst figure by more than noise
+    sustained = L.capi.hbm_sustained(0, 256 << 20, 50)
+    assert 1000.0 < sustained < 1.15 * best, (sustained, best)
