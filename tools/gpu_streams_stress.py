@@ -26,6 +26,12 @@ for algo, poll in (("sp", 0), ("ms", 2), ("layered", 0)):
 bad = 0
 for rnd in range(rounds):
     for algo, poll in (("sp", 0), ("ms", 2), ("layered", 0)):
+        # as the test does: fresh channel values on the device and their copy to the host, every time
+        y = channel.awgn_device(N, 0, B, 0.8, seed=61, device=0)
+        yh2 = y.cpu().numpy()
+        if not np.array_equal(yh2, yh):
+            bad += 1
+            print("MISMATCH channel", rnd, flush=True)
         for streams in (2, 3):
             dec = L.Decoder(g, K, max_batch=B, algo=algo, max_iter=20, layer_rows=z, poll_interval=poll, streams=streams,
                             tune={"fused": False, "ldsp": False} if algo != "layered" else None)
