@@ -22,8 +22,10 @@ Prints ONE JSON line (rank 0): metric/value/unit (whole-job Mbit/s), ms_per_step
 `roofline` for the dominant kernel (HIP-event time on the launch stream, live) and, at
 N = 1, `cpu_baseline` (the oracle's restatement of the reference's CPU decoder,
 MyLdpc.cpp:684-784, on a bounded sample), `extra` (BASELINE.json configs[3] and [4] at
-their full batch sizes), `ber` (BER @ SNR points, the other half of BASELINE's metric) and `host_path` (the reference's own signature: host buffers in,
-host buffers out, PCIe included).
+their full batch sizes), `ber` (BER @ SNR points, the other half of BASELINE's metric), `host_path` (the reference's own
+signature: host buffers in, host buffers out, PCIe included, in both input modes), `host_path_devices`
+(the same call on ONE handle over every visible GPU: `ldpc_decoder_create_multi`) and `coder_path` (the
+C++ class itself: Test.cpp's call sequence through libmyldpc.so, timed by `CoderBench`).
 """
 import argparse
 import json
@@ -56,7 +58,7 @@ EXTRA_CONFIGS = {
 }
 
 
-def measure_extra(name, steps, warmup, batch=0, sigma=0.0, fpl=0, poll=-1, tune=None, streams=0):
+def measure_extra(name, steps, warmup, batch=0, sigma=0.0, fpl=0, poll=-1, tune=None):
     """One extra config on the current GPU: dict with the headline fields of its own."""
     import numpy as np
     import torch
@@ -80,10 +82,7 @@ def measure_extra(name, steps, warmup, batch=0, sigma=0.0, fpl=0, poll=-1, tune=
         c = dict(c, poll=poll, desc=c["desc"] + " [poll_interval %d]" % poll)
     g = L.Graph(rows, cols, M, N)
     dec = L.Decoder(g, K, max_batch=B, algo=c["algo"], max_iter=c["iters"], early_term=c["early"],
-                    layer_rows=layer, msg_dtype=c["msg"], poll_interval=c["poll"], frames_per_lane=fpl, tune=tune,
-                    streams=streams)
-    if streams > 1:
-        c = dict(c, desc=c["desc"] + " [%d streams]" % streams)
+                    layer_rows=layer, msg_dtype=c["msg"], poll_interval=c["poll"], frames_per_lane=fpl, tune=tune)
     y = channel.awgn_device(N, 0, B, c["sigma"], seed=SEED)
     out = torch.empty(L.out_bytes(K, B), dtype=torch.uint8, device="cuda")
     it = torch.empty(B, dtype=torch.int32, device="cuda")
@@ -136,72 +135,83 @@ def measure_extra(name, steps, warmup, batch=0, sigma=0.0, fpl=0, poll=-1, tune=
     return res
 
 
-def host_path(g, groups=3, B=BATCH_PER_GPU):
+def host_path(g, groups=3, B=BATCH_PER_GPU, devices=None, modes=("staged", "lock_pages"), gen_device=0):
     """The reference's own signature (`Coder::decode` -> `ldpc_decode`): host buffers in, host
-    buffers out, `groups` x B frames, sum-product at full work -- PCIe transfers included."""
+    buffers out, `groups` x B frames per device, sum-product at full work -- PCIe transfers included.
+    devices = None: one decoder on the current GPU; a list: ONE handle over those GPUs
+    (`ldpc_decoder_create_multi`), the frame stream cut into one contiguous range per device."""
+    import numpy as np
     import torch
     import myldpccppapi_amd as L
     from myldpccppapi_amd import channel
-    frames = groups * B
+    ndev = len(devices) if devices else 1
+    frames = groups * B * ndev
     y_host = torch.empty((frames, N_CODE), dtype=torch.float32)         # pageable, as a caller's malloc
-    for k in range(groups):
-        y_host[k * B:(k + 1) * B] = channel.awgn_device(N_CODE, k * B, B, SIGMA, seed=SEED).cpu()
+    for k in range(groups * ndev):
+        y_host[k * B:(k + 1) * B] = channel.awgn_device(N_CODE, k * B, B, SIGMA, seed=SEED, device=gen_device).cpu()
     torch.cuda.empty_cache()
-    dec = L.Decoder(g, K_CODE, max_batch=B, algo="sp", max_iter=ITERS, llr_scale=8.0, early_term=True)
     ynp = y_host.numpy()
-    dec.decode(ynp[:64], want_iters=False)                                # staging slots, first-touch
-    times = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        out, _ = dec.decode(ynp, want_iters=False)
-        times.append(time.perf_counter() - t0)
-    dec.close()
-    dt = min(times)
-    return {"value": round(frames * K_CODE / dt / 1e6, 2), "unit": "Mbit/s", "frames": frames,
-            "ms": round(dt * 1e3, 2), "first_call_ms": round(times[0] * 1e3, 2), "calls": len(times), "max_batch": B,
-            "what": "ldpc_decode (Coder::decode's signature): %d frames from pageable host memory in %d groups of %d, "
-                    "sum-product fp32, %d iterations at full work, packed bytes back in host memory; H2D of group "
-                    "k+1 and D2H of group k-1 overlap the decode of group k; best of %d calls on the same buffer "
-                    "(the first one also pays for the first page-locking of the caller's pages: first_call_ms); "
-                    "tools/gpu_hostpath_scan.py: T(groups) = 19 ms + 126.5 ms per group"
-                    % (frames, groups, B, ITERS, len(times))}
-
-
-def streams_overlap(g, B, steps, warmup, algo, device=0):
-    """The headline workload with the batch cut into 2 and 4 frame ranges on streams of their own
-    (ldpc_decoder_config.streams): one range's kernels fill the GPU while another's kernel drains.  Same
-    frames, same bytes (checked against the single-stream output); reported beside the headline: the step has
-    two regimes (about 123 and 137 ms) and which cut of the batch gets which varies by box."""
-    import torch
-    import myldpccppapi_amd as L
-    from myldpccppapi_amd import channel
-    y = channel.awgn_device(N_CODE, 0, B, SIGMA, seed=SEED, device=device)
-    out = torch.empty(L.out_bytes(K_CODE, B), dtype=torch.uint8, device="cuda")
-    res, ref = {}, None
-    for streams in (1, 2, 4):
-        dec = L.Decoder(g, K_CODE, max_batch=B, algo=algo, max_iter=ITERS, llr_scale=8.0, early_term=True,
-                        device=device, streams=streams)
-        s = torch.cuda.current_stream().cuda_stream
-        for _ in range(max(1, warmup)):
-            dec.decode_device(y.data_ptr(), B, out.data_ptr(), out.numel(), None, s)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            dec.decode_device(y.data_ptr(), B, out.data_ptr(), out.numel(), None, s)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        o = out.cpu()
-        if ref is None:
-            ref = o
-        res[str(streams)] = {"value": round(B * K_CODE / dt / 1e6, 2), "unit": "Mbit/s", "ms_per_step": round(dt * 1e3, 3),
-                             "same_bytes_as_one_stream": bool(torch.equal(o, ref))}
-        dec.close()
-        del dec
-        torch.cuda.empty_cache()
-    res["what"] = ("the headline step (%d frames, %d iterations, %s) with ldpc_decoder_config.streams = 1, 2, 4: sub-decoders "
-                   "of %d / streams frames each on a stream of its own, same device; `steps` = %d untimed-kernel steps each"
-                   % (B, ITERS, algo, B, steps))
+    res = {"frames": frames, "max_batch": B, "devices": list(devices) if devices else None, "unit": "Mbit/s"}
+    first = None
+    for mode in modes:
+        dec = L.Decoder(g, K_CODE, max_batch=B, algo="sp", max_iter=ITERS, llr_scale=8.0, early_term=True,
+                        device=gen_device, devices=devices, host_input=mode)
+        dec.decode(ynp[:64 * ndev], want_iters=False)                     # staging slots, first-touch
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            out, _ = dec.decode(ynp, want_iters=False)
+            times.append(time.perf_counter() - t0)
+        dec.close()                                                       # raises if a page-locked block was left behind
+        if first is None:
+            first = out
+        dt = min(times)
+        res[mode] = {"value": round(frames * K_CODE / dt / 1e6, 2), "ms": round(dt * 1e3, 2),
+                     "first_call_ms": round(times[0] * 1e3, 2), "calls": len(times),
+                     "same_bytes_as_first_mode": bool(np.array_equal(out, first))}
+    res["value"] = res[modes[0]]["value"]
+    res["locked_ranges_left"] = list(L.capi.host_locked_ranges())
+    res["what"] = ("ldpc_decode (Coder::decode's signature): %d frames from pageable host memory, %d groups of %d per "
+                   "device, sum-product fp32, %d iterations at full work, packed bytes back in host memory; the copy-in of "
+                   "group k+1 and the copy-out of group k-1 overlap the decode of group k; best of 3 calls on the same buffer.  "
+                   "staged (the default) = the handle's copy threads move each group through the library's pinned ring; "
+                   "lock_pages (opt-in) = the caller's pages are page-locked for the call and read in place"
+                   % (frames, groups, B, ITERS))
     return res
+
+
+def coder_path(frames=BATCH_PER_GPU, iters=40, snr=2.6, repeat=3, timeout=600):
+    """The C++ class as a Test.cpp user sees it (Test.cpp:47-64,105-112): Coder(32400, 64800, rate_1_2)
+    -- the reference-constructible code of the headline size, z = 2700, E = 205200 -- forEncoder, encode,
+    test, addDecodeType(DecodeSP), decode of `frames` frames at the reference's 40 iterations, through
+    libmyldpc.so in a process of its own (myldpccppapi_amd/CoderBench), wall clock."""
+    exe = os.path.join(ROOT, "myldpccppapi_amd", "CoderBench")
+    if not os.path.exists(exe):
+        return {"error": "%s not built" % exe}
+    cmd = [exe, "0", str(N_CODE), str(frames), str(frames), str(snr), "SP", "--iters", str(iters), "--repeat", str(repeat)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    if p.returncode != 0:
+        return {"error": "rc %d: %s" % (p.returncode, (p.stderr or p.stdout)[-400:])}
+    kv = {}
+    for ln in p.stdout.splitlines():
+        if "=" in ln:
+            k, v = ln.split("=", 1)
+            kv[k.strip()] = v.strip()
+    dec = sorted(float(v) for k, v in kv.items() if k.startswith("decode_s["))
+    first = float(kv.get("decode_s[0]", "nan"))
+    return {"value": float(kv["decode_info_mbit_s"]), "unit": "Mbit/s", "frames": frames, "batchSize": frames,
+            "iterations": iters, "decodeType": "DecodeSP", "K": int(kv["K"]), "N": int(kv["N"]), "z": int(kv["z"]),
+            "NonZeros": int(kv["NonZeros"]), "sd": float(kv["sd"]), "Time": int(kv["Time"]), "ErrNum": int(kv["ErrNum"]),
+            "ThroughPut_bytes_per_s": float(kv["ThroughPut"]), "decode_ms_best": round(dec[0] * 1e3, 2),
+            "decode_ms_first_call": round(first * 1e3, 2), "decode_calls": len(dec),
+            "forEncoder_ms": round(float(kv["forEncoder_s"]) * 1e3, 3), "encode_ms": round(float(kv["encode_s"]) * 1e3, 2),
+            "encode_info_mbit_s": float(kv["encode_info_mbit_s"]), "test_ms": round(float(kv["test_s"]) * 1e3, 1),
+            "addDecodeType_ms": round(float(kv["addDecodeType_s"]) * 1e3, 1),
+            "what": "CoderBench 0 %d %d %d %.1f SP --iters %d: Test.cpp's sequence on Coder(32400, 64800, rate_1_2); decode() = "
+                    "ldpc_decode with poll_interval 4 from malloc'ed buffers (default input mode: staged), PCIe included; "
+                    "ThroughPut = info bytes per wall-clock second of the best of %d decode() calls (the reference prints "
+                    "CPU seconds, Test.cpp:111); encode() is the structured O(E) encoder, single-threaded on the host"
+                    % (N_CODE, frames, frames, snr, iters, repeat)}
 
 
 def ber_points(g, B=BATCH_PER_GPU):
@@ -319,7 +329,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the config's)")
-    ap.add_argument("--config", default="dvbs2_sp", choices=["dvbs2_sp", "streams_probe"] + sorted(EXTRA_CONFIGS),
+    ap.add_argument("--config", default="dvbs2_sp", choices=["dvbs2_sp"] + sorted(EXTRA_CONFIGS),
                     help="dvbs2_sp = the headline workload (default); others are extra measurement points")
     ap.add_argument("--algo", default="sp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -329,7 +339,6 @@ def main():
     ap.add_argument("--sigma", type=float, default=0.0, help="extra configs: noise level override")
     ap.add_argument("--fpl", type=int, default=0, help="frames per lane override (tuning)")
     ap.add_argument("--poll", type=int, default=-1, help="extra configs: poll_interval override (0 = asynchronous)")
-    ap.add_argument("--streams", type=int, default=0, help="ldpc_decoder_config.streams (experiments; the headline is single-stream)")
     ap.add_argument("--tune", default="", help='tuning fields as JSON, e.g. \'{"merge": false}\' (A/B experiments)')
     args = ap.parse_args()
 
@@ -355,19 +364,14 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # a CPU-side group for waiting WITHOUT a spinning kernel on the GPU (rank 0's device-list measurement at the end)
+    cpu_group = dist.new_group(backend="gloo") if world > 1 else None
 
-    if args.config == "streams_probe":      # the `streams` block of the headline line, in a process of its own
-        import myldpccppapi_amd as L
-        from myldpccppapi_amd import codes
-        rows, cols = codes.dvbs2_profile_edges(N_CODE, K_CODE)
-        g = L.Graph(rows, cols, N_CODE - K_CODE, N_CODE)
-        print(json.dumps(streams_overlap(g, args.batch or BATCH_PER_GPU, args.steps, args.warmup, args.algo, local_rank)), flush=True)
-        return
     if args.config != "dvbs2_sp":
         if world > 1:
             sys.exit("extra configs are single-GPU measurements")
         print(json.dumps(measure_extra(args.config, args.steps, args.warmup, args.batch, args.sigma, args.fpl, args.poll,
-                                       json.loads(args.tune) if args.tune else None, args.streams)), flush=True)
+                                       json.loads(args.tune) if args.tune else None)), flush=True)
         return
 
     import myldpccppapi_amd as L
@@ -378,7 +382,7 @@ def main():
     g = L.Graph(rows, cols, N_CODE - K_CODE, N_CODE)
     dec = L.Decoder(g, K_CODE, max_batch=B, algo=args.algo, max_iter=ITERS, llr_scale=8.0,
                     early_term=True, device=local_rank, frames_per_lane=args.fpl,
-                    tune=json.loads(args.tune) if args.tune else None, streams=args.streams)
+                    tune=json.loads(args.tune) if args.tune else None)
     # synthetic channel: all-zero codeword + AWGN, generated in HBM, distinct per rank
     lo, hi = sharding.shard_range(B * world, rank, world)
     # (counter-based noise, csrc/ldpc_channel.h: frame lo + i of the seed's stream, whatever the world size)
@@ -429,14 +433,26 @@ def main():
     st = dec.stats()
     kt = dec.kernel_times()
     assert st["iterations_launched"] == ITERS
-    # frames one launch works on: the whole batch, or one stream's range (the kernel times are the first range's)
-    streams_on = args.streams > 1 and B >= 512 * args.streams and K_CODE % 8 == 0
-    launch_frames = ((B + args.streams - 1) // args.streams + 255) // 256 * 256 if streams_on else B
+    launch_frames = B
+    flood = [k for k in kt if k["phase"] in (0, 1)]
+    dom = max(flood, key=lambda k: k["ms_total"])
+    # what this rank's box delivers right now: float4 copy of 1 GiB, the better of the default cache policy and
+    # the streaming kernels' non-temporal one -- on EVERY rank, at the same moment, so that a GPU in a slow
+    # state shows in the record (ranks.per_rank)
+    try:
+        probe, probe_default, probe_nt = L.capi.hbm_probe(local_rank, 1 << 30, 5, by_policy=True)
+    except Exception:
+        probe = probe_default = probe_nt = None
+    mine = {"rank": rank, "device": local_rank, "ms_per_step": round(dt_own / args.steps * 1e3, 3),
+            "kernel": dom["name"], "avg_launch_ms": round(dom["ms_total"] / dom["launches"], 4),
+            "hbm_probe_gbs": None if probe is None else round(probe, 1)}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if rank == 0:
         frames_total = B * world * args.steps
         value = frames_total * K_CODE / dt / 1e6
-        flood = [k for k in kt if k["phase"] in (0, 1)]
-        dom = max(flood, key=lambda k: k["ms_total"])
         dom_avg_ms = dom["ms_total"] / dom["launches"]
         # bytes the dominant kernel's own loads and stores move per launch (for the column-fused check
         # kernel: less than its share of 16 E + 4 N, the fused columns' messages stay in registers) ...
@@ -461,12 +477,7 @@ def main():
                                                                  "" if tc["frames_per_gpu"] == launch_frames else ", scaled to %d" % launch_frames))
             except Exception:
                 traffic = None
-        probe = None
-        try:
-            probe, probe_default, probe_nt = L.capi.hbm_probe(local_rank, 1 << 30, 5, by_policy=True)
-        except Exception:
-            probe = probe_default = probe_nt = None
-        # ... and what the box SUSTAINS right now, the GPU still hot from the timed steps: the same copy back to
+        # what the box SUSTAINS right now, the GPU still hot from the timed steps: the same copy back to
         # back for 0.3 s (these boxes drop to about 5.2 TB/s under load at times; a burst does not see it)
         try:
             sustained = L.capi.hbm_sustained(local_rank, 1 << 30, 300)
@@ -485,7 +496,7 @@ def main():
                             "(probability domain), all-zero codeword + AWGN sigma=%.2f (no frame converges), "
                             "early termination on, inputs resident in HBM" % (B, ITERS, SIGMA),
                 "global_batch": B * world, "frames_per_gpu": B, "iterations": ITERS, "algo": args.algo,
-                "streams": args.streams if streams_on else 1, "frames_per_launch": launch_frames,
+                "frames_per_launch": launch_frames,
                 "parallelism": "frames sharded over %d GPU(s), all-gather of decoded bytes" % world,
                 "coded_mbit_s": round(value * N_CODE / K_CODE, 2),
                 "frames_converged": st["frames_converged"],
@@ -493,7 +504,10 @@ def main():
             "ranks": {"world_size": dist.get_world_size() if world > 1 else 1,
                       "backend": ("gloo (rehearsal)" if rehearsal else "nccl (RCCL)") if world > 1 else None,
                       "self_launched": os.environ.get("LDPC_BENCH_SELF_LAUNCHED") == "1",
-                      "ms_per_step_min": round(min(per_rank_ms), 3), "ms_per_step_max": round(max(per_rank_ms), 3)},
+                      "ms_per_step_min": round(min(per_rank_ms), 3), "ms_per_step_max": round(max(per_rank_ms), 3),
+                      # one entry per rank: its own step time, its dominant kernel's HIP-event launch time and the
+                      # copy rate its GPU delivered right after the timed steps
+                      "per_rank": per_rank},
             "roofline": {
                 "bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -552,28 +566,40 @@ def main():
                 except Exception as e:      # an extra point must never cost the headline line
                     extra[key] = {"error": repr(e)}
             res["extra"] = extra
-            # in a process of its own: nothing that happens there can cost the headline line
-            try:
-                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "streams_probe", "--batch", str(B),
-                                    "--steps", str(max(3, args.steps // 2)), "--warmup", "1", "--algo", args.algo],
-                                   capture_output=True, text=True, timeout=300,
-                                   env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
-                line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-                res["streams"] = json.loads(line[-1]) if p.returncode == 0 and line else {"error": "rc %d: %s" % (p.returncode, p.stderr[-300:])}
-            except Exception as e:
-                res["streams"] = {"error": repr(e)}
             try:
                 res["ber"] = ber_points(g)
             except Exception as e:
                 res["ber"] = {"error": repr(e)}
             try:
-                res["host_path"] = host_path(g)
+                res["host_path"] = host_path(g, B=B, gen_device=local_rank)
             except Exception as e:
                 res["host_path"] = {"error": repr(e)}
+            try:
+                res["coder_path"] = coder_path()
+            except Exception as e:
+                res["coder_path"] = {"error": repr(e)}
+        if not args.no_extras:
+            # the drop-in signature over a device list: ONE handle over every visible GPU, rank 0 only (the other
+            # ranks have released their GPUs' memory and wait at the barrier below)
+            if world > 1:
+                dec.close()
+                del y, out, gathered
+                torch.cuda.empty_cache()
+                dist.barrier(group=cpu_group)           # every rank has released its GPU's memory
+            try:
+                devs = list(range(torch.cuda.device_count())) if not rehearsal else [local_rank]
+                res["host_path_devices"] = host_path(g, B=B, devices=devs, modes=("staged",), gen_device=local_rank)
+            except Exception as e:
+                res["host_path_devices"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
+    elif world > 1 and not args.no_extras:
+        dec.close()
+        del y, out, gathered
+        torch.cuda.empty_cache()
+        dist.barrier(group=cpu_group)
     dec.close()
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=cpu_group)                   # rank 0 may still be measuring host_path_devices: wait on the CPU
         dist.destroy_process_group()
 
 

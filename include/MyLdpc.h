@@ -20,9 +20,13 @@
  *   - DecodeCPU runs the same min-sum arithmetic on the GPU (bit-identical to
  *     decodeCPU, MyLdpc.cpp:684-784, including its bit-offset packing); there is
  *     no CPU decode path in this library.
- *   - DecodeTDMP and DecodeTDMPCL both run the layered schedule with the
- *     semantics of the fused kernel (decodeCL.c:307-426); DecodeMSCL runs the fused
- *     flooding kernel's arithmetic (decodeCL.c:432-567, 120 iterations as there).
+ *   - DecodeTDMPCL runs the layered schedule with the semantics of the fused kernel
+ *     (decodeCL.c:307-426).  DecodeTDMP follows the reference's HOST-driven layered path
+ *     (MyLdpc.cpp:889-976 over decodeCL.c:203-300) operation for operation on the seeds where
+ *     that path is a decode of H -- every row of one weight: rates 2/3A and 5/6; the reference
+ *     sizes layer l as hRowRange[l+z]-hRowRange[l], :907,958 -- and falls back to the fused
+ *     kernel's semantics on the other four.  DecodeMSCL runs the fused flooding kernel's
+ *     arithmetic (decodeCL.c:432-567, 120 iterations as there).
  *   - `times` (MyLdpc.cpp:24) and the SP channel scale 8 (decodeCL.c:9) stay the
  *     defaults and can be changed with setMaxIterations()/setLlrScale().
  *   - setDevices(): one Coder over several GPUs (the reference uses devices[0] only).
@@ -76,10 +80,10 @@ public:
      * ranges side by side, batchSize frames per device and launch group; bytes identical to the
      * single-device result.  Before addDecodeType(). */
     void setDevices(const int *ordinals, int count) { devices.assign(ordinals, ordinals + (count > 0 ? count : 0)); }
-    /* 2..8: every decoder cuts its launch group into that many frame ranges on streams of their own, same
-     * device (ldpc_decoder_config.streams: launch boundaries overlap; needs batchSize >= 512 per stream and
-     * K % 8 == 0, else one stream).  Before addDecodeType(). */
-    void setStreams(int n) { streams = n; }
+    /* How decode() moves the caller's (pageable) postCode to the devices: LDPC_HOST_INPUT_STAGED (default:
+     * through the library's own pinned ring) or LDPC_HOST_INPUT_LOCK_PAGES (page-locks the caller's pages
+     * for the call; include/ldpc_hip.h).  Before addDecodeType(). */
+    void setHostInput(int mode) { hostInput = mode; }
     int lastIterations() const { return lastTime; }             /* the reference's "Time=" */
     const char *lastError() const { return err.c_str(); }
     int getNonZeros() const { return nonZeros; }
@@ -98,7 +102,7 @@ private:
     float llrScale;
     int device;
     std::vector<int> devices;        /* setDevices(); empty: `device` alone */
-    int streams = 0;                 /* setStreams() */
+    int hostInput = 0;               /* setHostInput() */
     int makeDecoder(const ldpc_decoder_config &cfg, ldpc_decoder **out);
     const signed char *hSeed;
     int seedRowLength;

@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define LDPC_HIP_ABI_VERSION 2   /* 2: tuning fields in the config (were reserved[8]), device lists */
+#define LDPC_HIP_ABI_VERSION 3   /* 2: tuning fields in the config (were reserved[8]), device lists;
+                                    3: host_input / host_copy_threads replace the experimental `streams` */
 
 enum ldpc_status {
     LDPC_OK = 0,
@@ -72,6 +73,21 @@ enum ldpc_algo {
 };
 
 enum ldpc_msg_dtype { LDPC_MSG_F32 = 0, LDPC_MSG_F16 = 1 };
+
+/* ldpc_decode() and the caller's input buffer (the reference copies it with a blocking
+ * enqueueWriteBuffer, MyLdpc.cpp:796 / :988).
+ *   STAGED (the default): the library never hands the caller's pageable memory to the HIP runtime and
+ *     never changes its page state.  Worker threads owned by the handle copy each launch group, 8 MiB
+ *     at a time, into a ring of the library's own pinned buffers, from which it is DMA-copied to the
+ *     device while the previous group decodes.
+ *   LOCK_PAGES (opt-in): groups larger than 4 MiB are page-locked where they lie (hipHostRegister) for the
+ *     duration of the call and DMA-read in place: no CPU copy (worth it for long streams of cheap
+ *     decodes, where the CPU copy is slower than the decode).  Whole pages strictly inside the call's
+ *     own byte range only; every range is recorded process-wide, released before the call returns, and a
+ *     range that cannot be released makes the call -- and ldpc_decoder_destroy -- fail.  A group whose
+ *     pages cannot be locked (another call of this library holds them) is staged instead.
+ * In both modes groups of up to 4 MiB are copied by the calling thread into pinned scratch. */
+enum ldpc_host_input { LDPC_HOST_INPUT_AUTO = 0, LDPC_HOST_INPUT_STAGED = 1, LDPC_HOST_INPUT_LOCK_PAGES = 2 };
 
 enum ldpc_pack_mode {
     LDPC_PACK_BYTES = 0, /* toChar, decodeCL.c:188-199: K/8 whole bytes per frame at (frame*K)/8 */
@@ -112,13 +128,13 @@ typedef struct ldpc_decoder_config {
                                    (default and maximum 512); -1 = off                            */
     int32_t tune_ldsp_grid;     /* record kernels (ldsp_kernels.hpp): persistent workgroups        */
     int32_t tune_ldsp_shape;    /* workgroups per CU | waves per workgroup << 8                    */
-    int32_t streams;            /* 0 / 1: one decode stream.  2..8: the batch is cut into that many
-                                   contiguous frame ranges (multiples of 256 frames), each decoded by a
-                                   sub-decoder of its own on a stream of its own, on the same device:
-                                   the kernels of one range fill the GPU while another range's kernel
-                                   drains (launch boundaries cost 8 % of the headline step).  Same bytes
-                                   and iteration counts; ignored when max_batch < 512 per stream or K % 8 != 0.  Not a
-                                   tuning field of kernels: a property of the handle                  */
+    int32_t host_input;         /* enum ldpc_host_input: how ldpc_decode() moves the caller's pageable channel
+                                   values to the device (memory the caller has page-locked itself is always
+                                   copied from directly)                                               */
+    int32_t host_copy_threads;  /* LDPC_HOST_INPUT_STAGED: CPU threads that copy a launch group into the
+                                   library's pinned ring (0 = automatic: 4; 1..16).  They belong to the
+                                   handle: started on its first large host-buffer call, joined when it is
+                                   destroyed                                                           */
 } ldpc_decoder_config;
 
 /* two-bit fields of tune_flags: LDPC_TUNE_ON(f) forces the choice on, LDPC_TUNE_OFF(f) off */
@@ -190,7 +206,9 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
  * Device-pointer entry points (ldpc_decode_device, taps, dumps) need a single-device handle. */
 int ldpc_decoder_create_multi(const ldpc_graph *g, const ldpc_decoder_config *cfg, const int32_t *devices,
                               int32_t n_devices, ldpc_decoder **out);
-/* Waits for this handle's own work only (its streams), not for the device. */
+/* Waits for this handle's own work only (its streams), not for the device; joins the handle's worker
+ * threads.  Returns LDPC_ERR_STATE (after freeing the handle all the same) if a page-locked block of a
+ * caller's buffer could not be released by an earlier LDPC_HOST_INPUT_LOCK_PAGES call. */
 int ldpc_decoder_destroy(ldpc_decoder *d);
 /* Frames [*lo, *hi) of part `part` of `parts` when `frames` frames are cut into contiguous, balanced
  * ranges whose boundaries are multiples of `unit` frames (earlier parts take the remainder).  The
@@ -280,6 +298,16 @@ int ldpc_hbm_probe_device(int32_t device, int64_t bytes, int32_t reps, double *c
 /* The non-temporal copy back to back for `milliseconds` (the first third untimed): the rate the box SUSTAINS.
  * The boxes of this pool drop to about 5.2 TB/s under load at times while a burst still shows 6.4. */
 int ldpc_hbm_sustained_device(int32_t device, int64_t bytes, int32_t milliseconds, double *copy_gbs);
+
+/* ---- diagnostics of the host-buffer path (no device is touched) --------------------------------
+ * ldpc_host_block_plan: the page arithmetic of LDPC_HOST_INPUT_LOCK_PAGES for launch group `group` of a
+ *      call over `frames` frames of N floats, `max_batch` frames per group, first byte at address `base`:
+ *      out[0..1] = the group's bytes [s0, s1); out[2..3] = the page-locked block [b0, b1) (equal: none);
+ *      out[4] = end of the DMA-read body [b0, body_end); out[5] = 1 if the CPU copies the whole group.
+ * ldpc_host_locked_ranges: ranges of caller memory this library holds page-locked right now (*live,
+ *      0 between calls) and ranges it failed to release (*stale, 0 unless hipHostUnregister failed). */
+int ldpc_host_block_plan(uint64_t base, int64_t frames, int32_t N, int32_t max_batch, int64_t group, uint64_t out[6]);
+int ldpc_host_locked_ranges(int64_t *live, int64_t *stale);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,8 @@ class DecoderConfig(ctypes.Structure):
                 ("tune_flags", ctypes.c_int32), ("tune_rows_per_wave", ctypes.c_int32),
                 ("tune_cols_per_wave", ctypes.c_int32), ("tune_link_rows", ctypes.c_int32),
                 ("tune_compact", ctypes.c_int32), ("tune_ldsp_grid", ctypes.c_int32),
-                ("tune_ldsp_shape", ctypes.c_int32), ("streams", ctypes.c_int32)]
+                ("tune_ldsp_shape", ctypes.c_int32), ("host_input", ctypes.c_int32),
+                ("host_copy_threads", ctypes.c_int32)]
 
 
 class DecodeStats(ctypes.Structure):
@@ -59,6 +60,7 @@ EXPORTS = (
     "ldpc_decoder_create_multi", "ldpc_shard_range", "ldpc_decoder_destroy", "ldpc_decode", "ldpc_decode_device", "ldpc_out_bytes",
     "ldpc_decoder_set_timing", "ldpc_decoder_stats", "ldpc_decoder_kernel_times", "ldpc_decoder_set_tap",
     "ldpc_decoder_dump", "ldpc_awgn_device", "ldpc_count_errors_device", "ldpc_hbm_probe_device", "ldpc_hbm_sustained_device",
+    "ldpc_host_block_plan", "ldpc_host_locked_ranges",
 )
 
 
@@ -111,6 +113,9 @@ def load():
     L.ldpc_hbm_sustained_device.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
     L.ldpc_hbm_probe_device.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32,
                                         ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    L.ldpc_host_block_plan.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                       ctypes.POINTER(ctypes.c_uint64)]
+    L.ldpc_host_locked_ranges.argtypes = [i64p, i64p]
     _lib = L
     return L
 

@@ -14,6 +14,7 @@ from ._lib import DecoderConfig, DecodeStats, LdpcError  # noqa: F401
 ALGO_SP, ALGO_MS, ALGO_LAYERED, ALGO_MS_FUSED, ALGO_LAYERED_HOST = 0, 1, 2, 3, 4
 MSG_F32, MSG_F16 = 0, 1
 PACK_BYTES, PACK_BITS = 0, 1
+HOST_INPUT = {"auto": 0, "staged": 1, "lock_pages": 2}     # enum ldpc_host_input
 ALGOS = {"sp": ALGO_SP, "ms": ALGO_MS, "layered": ALGO_LAYERED, "ms_fused": ALGO_MS_FUSED,
          "layered_host": ALGO_LAYERED_HOST}
 
@@ -93,6 +94,20 @@ def shard_range(frames, part, parts, unit=1):
     return lo.value, hi.value
 
 
+def host_block_plan(base, frames, N, max_batch, group):
+    """ldpc_host_block_plan: (s0, s1, b0, b1, body_end, whole_by_cpu) of launch group `group` in lock mode."""
+    out = (ctypes.c_uint64 * 6)()
+    _lib.check(_lib.load().ldpc_host_block_plan(int(base), int(frames), int(N), int(max_batch), int(group), out))
+    return tuple(int(x) for x in out)
+
+
+def host_locked_ranges():
+    """(live, stale): ranges of caller memory the library holds page-locked now / failed to release."""
+    a, b = ctypes.c_int64(-1), ctypes.c_int64(-1)
+    _lib.check(_lib.load().ldpc_host_locked_ranges(ctypes.byref(a), ctypes.byref(b)))
+    return a.value, b.value
+
+
 def device_count():
     n = ctypes.c_int(0)
     rc = _lib.load().ldpc_device_count(ctypes.byref(n))
@@ -145,7 +160,7 @@ class Decoder:
 
     def __init__(self, graph, K, max_batch, algo="sp", max_iter=40, llr_scale=8.0, early_term=True,
                  device=0, layer_rows=0, pack_mode=PACK_BYTES, frames_per_lane=0, poll_interval=0,
-                 msg_dtype=MSG_F32, tune=None, devices=None, streams=0):
+                 msg_dtype=MSG_F32, tune=None, devices=None, host_input="auto", host_copy_threads=0):
         L = _lib.load()
         cfg = DecoderConfig()
         L.ldpc_decoder_config_init(ctypes.byref(cfg))
@@ -156,7 +171,10 @@ class Decoder:
         cfg.early_term, cfg.device, cfg.layer_rows = int(bool(early_term)), int(device), int(layer_rows)
         cfg.pack_mode, cfg.frames_per_lane, cfg.poll_interval = int(pack_mode), int(frames_per_lane), int(poll_interval)
         apply_tune(cfg, tune)
-        cfg.streams = int(streams)      # > 1: sub-decoders on streams of their own, same device (ldpc_hip.h)
+        # how ldpc_decode() moves pageable channel values: through the library's pinned ring (default) or by
+        # page-locking the caller's pages for the call (include/ldpc_hip.h: enum ldpc_host_input)
+        cfg.host_input = HOST_INPUT[host_input] if isinstance(host_input, str) else int(host_input)
+        cfg.host_copy_threads = int(host_copy_threads)
         self.cfg = cfg
         self.graph = graph
         self.K, self.N, self.E = int(K), graph.N, graph.E
@@ -214,9 +232,10 @@ class Decoder:
         return a
 
     def close(self):
+        """ldpc_decoder_destroy; raises if the library reports page-locked blocks it could not release."""
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None and _lib._lib is not None:
-            _lib._lib.ldpc_decoder_destroy(h)
+            _lib.check(_lib._lib.ldpc_decoder_destroy(h))
 
     def __del__(self):
         try:

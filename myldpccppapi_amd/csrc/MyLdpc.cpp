@@ -228,7 +228,7 @@ int Coder::forDecoder(int batchSize)
 int Coder::makeDecoder(const ldpc_decoder_config &cfg0, ldpc_decoder **out)
 {
     ldpc_decoder_config cfg = cfg0;
-    cfg.streams = (streams >= 2 && streams <= 8) ? streams : 0;
+    cfg.host_input = hostInput;
     if (devices.empty()) return ldpc_decoder_create(graph, &cfg, out);
     return ldpc_decoder_create_multi(graph, &cfg, devices.data(), (int)devices.size(), out);
 }

@@ -46,6 +46,7 @@
 #include "engines.hpp"
 #include "channel_kernels.hpp"
 #include "tune.hpp"
+#include "host_stage.hpp"
 
 namespace {
 
@@ -237,7 +238,21 @@ struct ldpc_decoder {
     } slot[3];
     bool suppress_poll = false;
     int32_t *h_active = nullptr;        /* pinned */
-    uint8_t *h_bounce = nullptr;        /* pinned, 4 MiB: input blocks that could not be page-locked */
+    /* LDPC_HOST_INPUT_STAGED: a ring of pinned chunks the caller's channel values pass through, filled by
+     * the stager thread (and its copy helpers) while the calling thread enqueues -- or, with polling,
+     * sits in -- the previous group's decode.  Threads and ring are made by the first large host-buffer
+     * call and live until the handle is destroyed. */
+    struct RingChunk { uint8_t *h = nullptr; hipEvent_t ev = nullptr; bool used = false; };
+    std::vector<RingChunk> ring;
+    size_t ring_next = 0;
+    std::unique_ptr<ldpc::Worker> stager;
+    std::vector<std::unique_ptr<ldpc::Worker>> copy_helpers;
+    std::vector<ldpc::Job> copy_jobs;   /* one per helper, reused chunk after chunk */
+    ldpc::Job stage_job[3];             /* one per slot */
+    bool stage_pending[3] = {false, false, false};
+    /* LDPC_HOST_INPUT_LOCK_PAGES: blocks of the caller's buffer this handle has page-locked (empty between
+     * calls), and blocks it could not release (reported by the call and by ldpc_decoder_destroy) */
+    std::vector<void *> locked_blocks, stuck_blocks;
     /* tail compaction (flood_kernels.hpp): a V = 1, one-tile decoder that takes over the last running
      * frames of a polled, early-terminating decode */
     ldpc_decoder *child = nullptr;
@@ -277,23 +292,26 @@ struct ldpc_decoder {
     DevBuf<int32_t> summary;            /* [2]: max iters, converged count */
 
     /* a handle over several devices (ldpc_decoder_create_multi): one single-device decoder per entry
-     * of the device list; this object then owns no device state of its own */
+     * of the device list, and one persistent host thread per entry that runs its frame range; this
+     * object then owns no device state of its own */
     std::vector<ldpc_decoder *> shards;
-    /* cfg.streams > 1: the shards are sub-decoders on ONE device, each with max_batch / streams frames and
-     * its own stream; such a handle also takes device pointers (ldpc_decode_device) */
-    bool one_device = false;
-    int64_t shard_frames = 0;           /* frames a sub-decoder holds */
-    hipEvent_t ev_in = nullptr;         /* the caller's stream at the start of a device-pointer call */
+    std::vector<std::unique_ptr<ldpc::Worker>> shard_workers;
 
     ~ldpc_decoder()
     {
-        if (ev_in) (void)hipEventDestroy(ev_in);
+        /* threads first: nothing of this handle runs any more when its streams and buffers go */
+        for (auto &w : shard_workers) w->stop();
+        if (stager) stager->stop();
+        for (auto &w : copy_helpers) w->stop();
         for (ldpc_decoder *sh : shards) (void)ldpc_decoder_destroy(sh);
         for (auto &s : spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
         if (ev_begin) (void)hipEventDestroy(ev_begin);
         if (ev_end) (void)hipEventDestroy(ev_end);
         if (h_active) (void)hipHostFree(h_active);
-        if (h_bounce) (void)hipHostFree(h_bounce);
+        for (auto &rc : ring) {
+            if (rc.h) (void)hipHostFree(rc.h);
+            if (rc.ev) (void)hipEventDestroy(rc.ev);
+        }
         if (h_summary) (void)hipHostFree(h_summary);
         if (ev_summary) (void)hipEventDestroy(ev_summary);
         for (auto &sl : slot) {
@@ -1004,32 +1022,6 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
         return fail(LDPC_ERR_HIP, "device %d not present (%d HIP devices)", cfg->device, ndev);
     HIP_TRY(hipSetDevice(cfg->device));
 
-    /* several streams: a handle over sub-decoders of max_batch / streams frames (whole tiles of any
-     * layout: multiples of 256 frames).  Not for K % 8 != 0, where a frame's first byte depends on the
-     * launch group it falls into (shard_unit below). */
-    if (cfg->streams > 1 && (int64_t)cfg->max_batch >= 512 * (int64_t)cfg->streams && cfg->K % 8 == 0 && !t_creating_child) {
-        const int64_t per = (((int64_t)cfg->max_batch + cfg->streams - 1) / cfg->streams + 255) / 256 * 256;
-        ldpc_decoder *grp = new (std::nothrow) ldpc_decoder;
-        if (!grp) return fail(LDPC_ERR_NOMEM, "out of memory");
-        std::unique_ptr<ldpc_decoder> guard(grp);
-        for (int32_t i = 0; i < cfg->streams; ++i) {
-            ldpc_decoder_config c = *cfg;
-            c.streams = 0;
-            c.max_batch = (int32_t)per;
-            ldpc_decoder *sh = nullptr;
-            const int rc = ldpc_decoder_create(g, &c, &sh);
-            if (rc) return rc;                   /* the guard destroys the sub-decoders made so far */
-            grp->shards.push_back(sh);
-        }
-        grp->cfg = *cfg;
-        grp->M = g->M; grp->N = g->N; grp->E = g->E;
-        grp->one_device = true;
-        grp->shard_frames = per;
-        HIP_TRY(hipEventCreateWithFlags(&grp->ev_in, hipEventDisableTiming));
-        *out = guard.release();
-        return LDPC_OK;
-    }
-
     ldpc_decoder *d = new (std::nothrow) ldpc_decoder;
     if (!d) return fail(LDPC_ERR_NOMEM, "out of memory");
     std::unique_ptr<ldpc_decoder> guard(d);
@@ -1208,13 +1200,21 @@ static void wait_for_own_work(ldpc_decoder *d)
 int ldpc_decoder_destroy(ldpc_decoder *d)
 {
     if (!d) return LDPC_OK;
+    /* blocks of caller memory an LDPC_HOST_INPUT_LOCK_PAGES call could not release: said loudly, here too */
+    size_t stuck = d->stuck_blocks.size() + d->locked_blocks.size();
+    for (ldpc_decoder *sh : d->shards) stuck += sh->stuck_blocks.size() + sh->locked_blocks.size();
     if (d->shards.empty()) {
         wait_for_own_work(d);
         ldpc::layered_plan_destroy(&d->layered);
         ldpc::fused_plan_destroy(&d->fused);
         ldpc::ldsp_plan_destroy(&d->ldsp);
     }
-    delete d;            /* a multi-device handle destroys its per-device decoders here */
+    delete d;            /* joins the handle's threads; a multi-device handle destroys its per-device decoders here */
+    if (stuck) {
+        fprintf(stderr, "ldpc_decoder_destroy: %zu page-locked block(s) of caller memory were never released\n", stuck);
+        return fail(LDPC_ERR_STATE, "%zu page-locked block(s) of caller memory could not be released "
+                    "(hipHostUnregister failed in an earlier ldpc_decode)", stuck);
+    }
     return LDPC_OK;
 }
 
@@ -1244,11 +1244,14 @@ int ldpc_decoder_create_multi(const ldpc_graph *g, const ldpc_decoder_config *cf
     for (int32_t i = 0; i < n_devices; ++i) {
         ldpc_decoder_config c = *cfg;
         c.device = devices[i];
-        c.streams = 0;                           /* a device list is the one level of ranges */
         ldpc_decoder *sh = nullptr;
         const int rc = ldpc_decoder_create(g, &c, &sh);
         if (rc) return rc;                       /* the guard destroys the shards made so far */
         grp->shards.push_back(sh);
+        /* the host thread that runs this device's frame range in every ldpc_decode of the handle */
+        grp->shard_workers.emplace_back(new (std::nothrow) ldpc::Worker([] { return g_err; }));
+        if (!grp->shard_workers.back() || !grp->shard_workers.back()->start())
+            return fail(LDPC_ERR_NOMEM, "cannot start the host thread of device-list entry %d", i);
     }
     grp->cfg = *cfg;
     grp->cfg.device = devices[0];
@@ -1257,88 +1260,13 @@ int ldpc_decoder_create_multi(const ldpc_graph *g, const ldpc_decoder_config *cf
     return LDPC_OK;
 }
 
-/* cfg.streams > 1: the frames are cut into one contiguous range per sub-decoder; every sub-decoder's
- * stream first waits for the caller's stream (its input is ready), and the caller's stream then waits for
- * every sub-decoder's last kernel, so the call keeps ldpc_decode_device's stream-ordered meaning.  A
- * sub-decoder that polls (poll_interval > 0) blocks its host thread: each range gets a thread of its own,
- * as the device-list path does; asynchronous ranges are simply enqueued one after the other. */
-static int decode_device_streams(ldpc_decoder *d, const float *llr_dev, int64_t frames, uint8_t *out_dev,
-                                 int64_t out_bytes, int32_t *iters_dev, void *stream)
-{
-    const int n = (int)d->shards.size();
-    if (frames < 0 || frames > d->cfg.max_batch)
-        return fail(LDPC_ERR_ARG, "frames=%lld outside [0, max_batch=%d]", (long long)frames, d->cfg.max_batch);
-    for (int i = 0; i < n; ++i) d->shards[i]->have_last = false;
-    if (frames == 0) { d->last_frames = 0; d->have_last = false; return LDPC_OK; }
-    if (!llr_dev) return fail(LDPC_ERR_ARG, "llr is NULL");
-    const int64_t need = ldpc_out_bytes(d->cfg.K, frames, d->cfg.pack_mode);
-    if (out_dev && out_bytes < need && d->cfg.pack_mode == LDPC_PACK_BITS)
-        return fail(LDPC_ERR_ARG, "out_bytes=%lld < %lld", (long long)out_bytes, (long long)need);
-    HIP_TRY(hipSetDevice(d->cfg.device));
-    hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipEventRecord(d->ev_in, s));
-    std::vector<int64_t> lo((size_t)n), hi((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        const int rc = ldpc_shard_range(frames, i, n, 256, &lo[i], &hi[i]);
-        if (rc) return rc;
-    }
-    std::vector<int> rcs((size_t)n, LDPC_OK);
-    std::vector<std::string> errs((size_t)n);
-    /* A call whose launches are timed (ldpc_decoder_set_timing) runs its ranges ONE AFTER THE OTHER: a
-     * launch's duration is a bandwidth figure only while the launch has the GPU to itself.  (Every
-     * sub-decoder counts its calls the same way, so the first one tells.) */
-    const bool blocking = d->cfg.poll_interval > 0 && d->cfg.early_term;
-    const ldpc_decoder *first = d->shards[0];
-    const bool timed_call = first->timing_every > 0 && (first->timing_calls % first->timing_every) == 0;
-    auto work = [&](int i) {
-        ldpc_decoder *sh = d->shards[i];
-        if (hi[i] <= lo[i]) return;
-        hipError_t we = hipSetDevice(d->cfg.device);
-        if (we == hipSuccess) we = hipStreamWaitEvent(sh->stream, d->ev_in, 0);
-        if (we == hipSuccess && timed_call && i > 0 && d->shards[i - 1]->have_last)
-            we = hipStreamWaitEvent(sh->stream, d->shards[i - 1]->ev_end, 0);
-        if (we != hipSuccess) {
-            rcs[i] = fail(LDPC_ERR_HIP, "stream %d: cannot wait for the caller's stream", i);
-            errs[i] = g_err;
-            return;
-        }
-        const int64_t base = lo[i] * (int64_t)d->cfg.K / 8;      /* exact: lo is a multiple of 256 */
-        const int64_t room = std::max<int64_t>(0, out_bytes - base);
-        rcs[i] = ldpc_decode_device(sh, llr_dev + (size_t)lo[i] * d->N, hi[i] - lo[i], out_dev ? out_dev + base : nullptr,
-                                    std::min(room, ldpc_out_bytes(d->cfg.K, hi[i] - lo[i], d->cfg.pack_mode)),
-                                    iters_dev ? iters_dev + lo[i] : nullptr, sh->stream);
-        if (rcs[i]) errs[i] = g_err;
-    };
-    std::vector<std::thread> threads;
-    std::vector<int> inline_work;
-    for (int i = 1; i < n; ++i) {
-        if (hi[i] <= lo[i]) continue;
-        if (!blocking || timed_call) { inline_work.push_back(i); continue; }     /* timed: in order, on this thread */
-        try { threads.emplace_back(work, i); }
-        catch (...) { inline_work.push_back(i); }
-    }
-    work(0);
-    for (int i : inline_work) work(i);
-    for (auto &t : threads) t.join();
-    /* the caller's stream continues when every range is done (also after an error: what was enqueued runs) */
-    for (int i = 0; i < n; ++i)
-        if (hi[i] > lo[i] && d->shards[i]->have_last) (void)hipStreamWaitEvent(s, d->shards[i]->ev_end, 0);
-    for (int i = 0; i < n; ++i)
-        if (rcs[i]) { g_err = errs[i]; return rcs[i]; }
-    d->have_last = true;
-    d->last_frames = frames;
-    d->last_stream = s;
-    return LDPC_OK;
-}
-
 int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, uint8_t *out_dev,
                        int64_t out_bytes, int32_t *iters_dev, void *stream)
 {
     if (!d) return fail(LDPC_ERR_ARG, "decoder is NULL");
-    if (!d->shards.empty() && !d->one_device)
+    if (!d->shards.empty())
         return fail(LDPC_ERR_STATE, "a multi-device handle decodes host buffers only (ldpc_decode): device "
                     "pointers belong to one device");
-    if (!d->shards.empty()) return decode_device_streams(d, llr_dev, frames, out_dev, out_bytes, iters_dev, stream);
     if (frames < 0 || frames > d->cfg.max_batch)
         return fail(LDPC_ERR_ARG, "frames=%lld outside [0, max_batch=%d]", (long long)frames,
                     d->cfg.max_batch);
@@ -1393,27 +1321,95 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
     return LDPC_OK;
 }
 
-/* Has the caller page-locked this memory itself (hipHostMalloc, hipHostRegister, a framework's pinned
- * allocator)?  Then it is locked as a whole, for longer than a decode call, and is copied from directly. */
-static bool caller_locked_memory(const void *p)
+/* ------------------------------------------------------------ host-buffer path
+ * ldpc_decode: the reference's Coder::decode signature (MyLdpc.cpp:571-618; its copies are the blocking
+ * enqueueWriteBuffer / enqueueReadBuffer of :796 and :988).  What moves the caller's channel values is
+ * chosen per call (enum ldpc_host_input, include/ldpc_hip.h):
+ *   direct -- the caller has page-locked the buffer itself: plain asynchronous copies;
+ *   staged -- the default: worker threads of the handle copy each launch group through a ring of this
+ *             library's own pinned chunks; the HIP runtime never sees the caller's pointer;
+ *   lock   -- opt-in: whole pages strictly inside the call's byte range are page-locked for the call
+ *             and read in place by the copy engine (host_stage.hpp: plan_group_blocks, PageLockRegistry).
+ * Groups of up to kStageBytes are copied by the calling thread into the slot's pinned scratch in the
+ * last two modes (one frame of the (648, 324) code is 2.6 KB: no thread hop on the latency path). */
+namespace {
+
+constexpr size_t kStageBytes = (size_t)4 << 20;
+constexpr size_t kRingChunk = (size_t)8 << 20;
+constexpr int kRingChunks = 4;
+
+enum InputMode { kInputDirect = 0, kInputStaged = 1, kInputLock = 2 };
+
+InputMode resolve_input_mode(const ldpc_decoder_config &cfg, const void *p, size_t bytes)
 {
-    /* any memory the runtime knows (page-locked host memory; also managed or device memory handed to the
-     * host-buffer entry point by mistake or on purpose) is left to the runtime's copy engine as it is */
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, p) == hipSuccess) return at.type != hipMemoryTypeUnregistered;
-    (void)hipGetLastError();
-    return false;
+    if (ldpc::PageLockRegistry::instance().caller_locked(p, (const uint8_t *)p + bytes - 1)) return kInputDirect;
+    return cfg.host_input == LDPC_HOST_INPUT_LOCK_PAGES ? kInputLock : kInputStaged;
 }
 
-/* groups up to this size are copied by the CPU into a pinned staging buffer of the slot (then DMA);
- * larger ones are DMA-read in place from pages locked for the call */
-constexpr size_t kStageBytes = (size_t)4 << 20;
+/* the pinned ring, the stager thread and its copy helpers: made once, by the first call that needs them */
+int ensure_stager(ldpc_decoder *d)
+{
+    if (d->stager) return LDPC_OK;
+    if (d->ring.empty()) d->ring.resize(kRingChunks);
+    for (auto &c : d->ring) {
+        if (!c.h) HIP_TRY(hipHostMalloc((void **)&c.h, kRingChunk, hipHostMallocDefault));
+        if (!c.ev) HIP_TRY(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming));
+    }
+    const int threads = d->cfg.host_copy_threads > 0 ? d->cfg.host_copy_threads : 4;
+    while ((int)d->copy_helpers.size() < threads - 1) {
+        std::unique_ptr<ldpc::Worker> w(new (std::nothrow) ldpc::Worker([] { return g_err; }));
+        if (!w || !w->start()) return fail(LDPC_ERR_NOMEM, "cannot start a copy thread");
+        d->copy_helpers.push_back(std::move(w));
+    }
+    d->copy_jobs.resize(d->copy_helpers.size());
+    std::unique_ptr<ldpc::Worker> st(new (std::nothrow) ldpc::Worker([] { return g_err; }));
+    if (!st || !st->start()) return fail(LDPC_ERR_NOMEM, "cannot start the staging thread");
+    d->stager = std::move(st);
+    return LDPC_OK;
+}
 
-/* ldpc_decode on ONE device.  pin_mode 0: ask here whether the caller has page-locked the buffer;
- * 1: it has not (a device list's parent asked once, before its threads lock anything); 2: it has --
- * plain copies. */
-static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t *out_host,
-                       int64_t out_bytes, int32_t *iters, int pin_mode)
+/* n bytes into a pinned chunk, the helpers taking equal page-aligned parts */
+void ring_fill(ldpc_decoder *d, uint8_t *dst, const uint8_t *src, size_t n)
+{
+    const size_t parts = d->copy_helpers.size() + 1;
+    if (parts == 1 || n < ((size_t)1 << 20)) { memcpy(dst, src, n); return; }
+    const size_t per = ((n + parts - 1) / parts + 4095) & ~(size_t)4095;
+    size_t used = 0;
+    for (size_t i = 0; i < d->copy_helpers.size(); ++i) {
+        const size_t lo = (i + 1) * per;
+        if (lo >= n) break;
+        const size_t len = std::min(per, n - lo);
+        d->copy_jobs[i].fn = [dst, src, lo, len]() -> int { memcpy(dst + lo, src + lo, len); return 0; };
+        d->copy_helpers[i]->submit(&d->copy_jobs[i]);
+        ++used;
+    }
+    memcpy(dst, src, std::min(per, n));
+    for (size_t i = 0; i < used; ++i) (void)d->copy_helpers[i]->wait(&d->copy_jobs[i]);
+}
+
+/* `bytes` from pageable memory to the device through the ring, on the copy stream.  One thread at a
+ * time per decoder (the stager thread; in lock mode the calling thread, for a block that could not be
+ * locked).  A chunk is reused once the copy that read it has completed. */
+hipError_t staged_copy(ldpc_decoder *d, uint8_t *dst, const uint8_t *src, size_t bytes)
+{
+    for (size_t o = 0; o < bytes; o += kRingChunk) {
+        const size_t n = std::min(kRingChunk, bytes - o);
+        auto &c = d->ring[d->ring_next++ % d->ring.size()];
+        hipError_t e = c.used ? hipEventSynchronize(c.ev) : hipSuccess;
+        if (e != hipSuccess) return e;
+        ring_fill(d, c.h, src + o, n);
+        e = hipMemcpyAsync(dst + o, c.h, n, hipMemcpyHostToDevice, d->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(c.ev, d->copy_stream);
+        if (e != hipSuccess) return e;
+        c.used = true;
+    }
+    return hipSuccess;
+}
+
+/* ldpc_decode on ONE device; `mode` was decided once per ldpc_decode call, before any thread of a device
+ * list has touched the buffer. */
+int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t *out_host,
+                int64_t out_bytes, int32_t *iters, InputMode mode)
 {
     const int64_t total = ldpc_out_bytes(d->cfg.K, frames, d->cfg.pack_mode);
     HIP_TRY(hipSetDevice(d->cfg.device));
@@ -1430,16 +1426,20 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
     if (!d->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < nslots; ++i) {
         auto &sl = d->slot[i];
-        if (sl.llr.p) continue;
-        HIP_TRY(sl.llr.alloc((size_t)B * d->N));
-        HIP_TRY(sl.out.alloc((size_t)stage_out));
-        HIP_TRY(sl.iters.alloc((size_t)B));
-        HIP_TRY(hipHostMalloc((void **)&sl.h_out, (size_t)stage_out, hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void **)&sl.h_iters, (size_t)B * sizeof(int32_t), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void **)&sl.h_head, kStageBytes, hipHostMallocDefault));
-        HIP_TRY(hipEventCreateWithFlags(&sl.h2d_done, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&sl.all_done, hipEventDisableTiming));
+        if (!sl.llr.p) HIP_TRY(sl.llr.alloc((size_t)B * d->N));
+        if (!sl.out.p) HIP_TRY(sl.out.alloc((size_t)stage_out));
+        if (!sl.iters.p) HIP_TRY(sl.iters.alloc((size_t)B));
+        if (!sl.h_out) HIP_TRY(hipHostMalloc((void **)&sl.h_out, (size_t)stage_out, hipHostMallocDefault));
+        if (!sl.h_iters) HIP_TRY(hipHostMalloc((void **)&sl.h_iters, (size_t)B * sizeof(int32_t), hipHostMallocDefault));
+        if (!sl.h_head) HIP_TRY(hipHostMalloc((void **)&sl.h_head, kStageBytes, hipHostMallocDefault));
+        if (!sl.h2d_done) HIP_TRY(hipEventCreateWithFlags(&sl.h2d_done, hipEventDisableTiming));
+        if (!sl.all_done) HIP_TRY(hipEventCreateWithFlags(&sl.all_done, hipEventDisableTiming));
     }
+    if (mode != kInputDirect && (size_t)std::min(B, frames) * d->N * sizeof(float) > kStageBytes) {
+        const int rs = ensure_stager(d);
+        if (rs) return rs;
+    }
+    ldpc::PageLockRegistry &registry = ldpc::PageLockRegistry::instance();
     /* a finished group's bytes go from the pinned slot to the caller's buffers */
     auto drain = [&](ldpc_decoder::HostSlot &sl) -> int {
         if (!sl.busy) return LDPC_OK;
@@ -1448,41 +1448,6 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
         if (sl.copy_bytes > 0) memcpy(out_host + sl.dst, sl.h_out, (size_t)sl.copy_bytes);
         if (iters) memcpy(iters + sl.off, sl.h_iters, (size_t)sl.n * sizeof(int32_t));
         return LDPC_OK;
-    };
-    /* A copy from pageable memory waits for the device's other work (measured: 151 ms behind a
-     * 140 ms decode instead of 19 ms), so the input never travels as a pageable source: a group of
-     * up to kStageBytes is copied by the CPU into the slot's pinned staging buffer, a larger one is
-     * page-locked where it lies for the duration of the call -- a true DMA that runs beside the
-     * previous group's kernels.  The rule that keeps this safe: the GPU only ever reads (a) this
-     * library's own pinned buffers and (b) WHOLE pages that this call has registered itself and that
-     * lie strictly inside its own byte range.
-     * Group k owns the block from its first page boundary up to the next group's first page boundary
-     * (the last group: up to its last page boundary); blocks are page-disjoint, each is registered
-     * just before its copy -- i.e. while the previous group decodes -- and all are released only
-     * after both streams have drained.  The bytes of a group before its first page boundary (and after
-     * the last group's last one) are read by the CPU into pinned scratch pages.  No pageable copy is
-     * issued from a buffer that has registered pages, neither by this call nor -- with a device list --
-     * by the threads working on the neighbouring ranges: the runtime resolves a host pointer through
-     * its table of locked ranges, and a pageable source next to (or starting inside) somebody's
-     * locked block ended in GPU memory faults twice during round 2.  A block that cannot be
-     * registered (already page-locked by the caller) is copied as the runtime sees fit. */
-    std::vector<void *> pinned;
-    const bool pin = pin_mode == 1 || (pin_mode == 0 && !caller_locked_memory(llr_host));
-    /* a block that cannot be locked goes through a pinned bounce buffer, chunk by chunk (slow, safe) */
-    auto bounce_copy = [&](uint8_t *dst, const uint8_t *src, size_t n) -> hipError_t {
-        constexpr size_t kChunk = (size_t)4 << 20;
-        if (!d->h_bounce) {
-            hipError_t e0 = hipHostMalloc((void **)&d->h_bounce, kChunk, hipHostMallocDefault);
-            if (e0 != hipSuccess) return e0;
-        }
-        for (size_t o = 0; o < n; o += kChunk) {
-            const size_t c = std::min(kChunk, n - o);
-            memcpy(d->h_bounce, src + o, c);
-            hipError_t e1 = hipMemcpyAsync(dst + o, d->h_bounce, c, hipMemcpyHostToDevice, d->copy_stream);
-            if (e1 == hipSuccess) e1 = hipStreamSynchronize(d->copy_stream);
-            if (e1 != hipSuccess) return e1;
-        }
-        return hipSuccess;
     };
     int rc = LDPC_OK;
 #ifdef LDPC_TRACE_HOST
@@ -1495,42 +1460,61 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
 #define LDPC_STAMP(what, kk) ((void)0)
 #endif
     /* Coder::decode, MyLdpc.cpp:577-616: groups of batchSize frames, last one short.
-     * stage_in(k): group k's channel values -> slot k % nslots, on the copy stream. */
+     * stage_in(k): group k's channel values -> slot k % nslots, on the copy stream (a copy from pageable
+     * memory handed to the runtime as it is would wait for the device's other work -- measured: 151 ms
+     * behind a 140 ms decode instead of 19 ms -- so the input never travels that way). */
     auto stage_in = [&](int64_t kk) -> int {
-        auto &sl = d->slot[kk % nslots];
+        const int si = (int)(kk % nslots);
+        auto &sl = d->slot[si];
         const int r1 = drain(sl);                /* the slot's previous tenant (group kk - nslots) */
         if (r1) return r1;
         const int64_t off = kk * B, n = std::min(B, frames - off);
         const uint8_t *src = reinterpret_cast<const uint8_t *>(llr_host + (size_t)off * d->N);
         const size_t bytes = (size_t)n * d->N * sizeof(float);
-        const uintptr_t s0 = (uintptr_t)src, s1 = s0 + bytes, b0 = (s0 + 4095) & ~(uintptr_t)4095;
-        hipError_t e = hipSuccess;
-        const bool last = kk + 1 == ngroups;
-        const uintptr_t b1 = last ? (s1 & ~(uintptr_t)4095) : ((s1 + 4095) & ~(uintptr_t)4095);   /* end of the block */
         uint8_t *dst = reinterpret_cast<uint8_t *>(sl.llr.p);
-        if (!pin) {
-            e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, d->copy_stream);           /* locked by the caller */
-        } else if (bytes <= kStageBytes || b0 >= b1) {
-            /* small group: the CPU copies it into the slot's pinned staging buffer */
+        hipError_t e = hipSuccess;
+        if (mode == kInputDirect) {
+            e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, d->copy_stream);
+        } else if (bytes <= kStageBytes) {
             memcpy(sl.h_head, src, bytes);
             e = hipMemcpyAsync(dst, sl.h_head, bytes, hipMemcpyHostToDevice, d->copy_stream);
+        } else if (mode == kInputStaged) {
+            ldpc::Job &job = d->stage_job[si];
+            hipEvent_t done = sl.h2d_done;
+            job.fn = [d, dst, src, bytes, done]() -> int {
+                hipError_t je = hipSetDevice(d->cfg.device);
+                if (je == hipSuccess) je = staged_copy(d, dst, src, bytes);
+                if (je == hipSuccess) je = hipEventRecord(done, d->copy_stream);
+                return je == hipSuccess ? LDPC_OK
+                                        : fail(LDPC_ERR_HIP, "staging through the pinned ring: %s", hipGetErrorString(je));
+            };
+            d->stager->submit(&job);
+            d->stage_pending[si] = true;
+            LDPC_STAMP("staging submitted", kk);
+            return LDPC_OK;                      /* the job records h2d_done */
         } else {
-            const size_t head = (size_t)(b0 - s0);
-            if (head) {
-                memcpy(sl.h_head, src, head);
-                e = hipMemcpyAsync(dst, sl.h_head, head, hipMemcpyHostToDevice, d->copy_stream);
+            const ldpc::GroupBlocks gb = ldpc::plan_group_blocks((uintptr_t)llr_host, frames, d->N, B, kk);
+            bool locked = false;
+            if (!gb.whole_by_cpu) {
+                bool overlap = false;
+                locked = registry.lock((void *)gb.b0, (size_t)(gb.b1 - gb.b0), &overlap) == hipSuccess;
+                if (locked) d->locked_blocks.push_back((void *)gb.b0);
             }
-            const bool locked = hipHostRegister((void *)b0, (size_t)(b1 - b0), hipHostRegisterPortable) == hipSuccess;
-            if (locked) pinned.push_back((void *)b0);
-            else (void)hipGetLastError();
-            const uintptr_t body_end = last ? b1 : s1;               /* the copy stops at the group's data */
-            const size_t body = (size_t)(body_end - b0), tail = (size_t)(s1 - body_end);
-            if (e == hipSuccess)
-                e = locked ? hipMemcpyAsync(dst + head, (const void *)b0, body, hipMemcpyHostToDevice, d->copy_stream)
-                           : bounce_copy(dst + head, (const uint8_t *)b0, body);
-            if (e == hipSuccess && tail) {
-                memcpy(sl.h_head + 4096, (const void *)body_end, tail);
-                e = hipMemcpyAsync(dst + head + body, sl.h_head + 4096, tail, hipMemcpyHostToDevice, d->copy_stream);
+            if (!locked) {
+                e = staged_copy(d, dst, src, bytes);      /* somebody else holds these pages: stage */
+            } else {
+                const size_t head = (size_t)(gb.b0 - gb.s0), body = (size_t)(gb.body_end - gb.b0),
+                             tail = (size_t)(gb.s1 - gb.body_end);
+                if (head) {
+                    memcpy(sl.h_head, src, head);
+                    e = hipMemcpyAsync(dst, sl.h_head, head, hipMemcpyHostToDevice, d->copy_stream);
+                }
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(dst + head, (const void *)gb.b0, body, hipMemcpyHostToDevice, d->copy_stream);
+                if (e == hipSuccess && tail) {
+                    memcpy(sl.h_head + ldpc::kPage, (const void *)gb.body_end, tail);
+                    e = hipMemcpyAsync(dst + head + body, sl.h_head + ldpc::kPage, tail, hipMemcpyHostToDevice, d->copy_stream);
+                }
             }
         }
         if (e == hipSuccess) e = hipEventRecord(sl.h2d_done, d->copy_stream);
@@ -1538,11 +1522,21 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
         LDPC_STAMP("H2D enqueued", kk);
         return LDPC_OK;
     };
+    /* the staging job of slot si has run: its copies and h2d_done are on the copy stream */
+    auto staged_ready = [&](int si) -> int {
+        if (!d->stage_pending[si]) return LDPC_OK;
+        d->stage_pending[si] = false;
+        const int r = d->stager->wait(&d->stage_job[si]);
+        if (r) g_err = d->stage_job[si].err;
+        return r;
+    };
     rc = stage_in(0);
     for (int64_t k = 0; k < ngroups && rc == LDPC_OK; ++k) {
-        auto &sl = d->slot[k % nslots];
+        const int si = (int)(k % nslots);
+        auto &sl = d->slot[si];
         const int64_t off = k * B, n = std::min(B, frames - off);
         if (k + 1 < ngroups && (rc = stage_in(k + 1))) break;   /* runs beside this group's decode */
+        if ((rc = staged_ready(si))) break;
         hipError_t e = hipStreamWaitEvent(d->stream, sl.h2d_done, 0);
         if (e != hipSuccess) { rc = fail(LDPC_ERR_HIP, "host-to-device staging: %s", hipGetErrorString(e)); break; }
         const int64_t chunk_bytes = ldpc_out_bytes(d->cfg.K, n, d->cfg.pack_mode);
@@ -1562,16 +1556,35 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
         sl.busy = true;
     }
 #undef LDPC_STAMP
-    const std::string first_error = rc ? g_err : std::string();
-    const int64_t k = ngroups;
-    for (int i = 0; i < nslots; ++i) {          /* oldest first: slot (k % nslots) was filled earliest */
-        const int r2 = drain(d->slot[(k + i) % nslots]);
-        if (rc == LDPC_OK) rc = r2;
+    std::string first_error = rc ? g_err : std::string();
+    /* every exit path: no staging job still reads the caller's buffer, nothing of this call is in flight */
+    for (int i = 0; i < nslots; ++i) {
+        const int r2 = staged_ready(i);
+        if (rc == LDPC_OK && r2) { rc = r2; first_error = g_err; }
     }
-    /* every exit path: nothing of this call is in flight any more when the pages are released */
-    (void)hipStreamSynchronize(d->copy_stream);
-    (void)hipStreamSynchronize(d->stream);
-    for (void *p : pinned) (void)hipHostUnregister(p);
+    for (int i = 0; i < nslots; ++i) {          /* oldest first: slot (ngroups % nslots) was filled earliest */
+        const int r2 = drain(d->slot[(ngroups + i) % nslots]);
+        if (rc == LDPC_OK && r2) { rc = r2; first_error = g_err; }
+    }
+    hipError_t es = hipStreamSynchronize(d->copy_stream);
+    const hipError_t es2 = hipStreamSynchronize(d->stream);
+    if (es == hipSuccess) es = es2;
+    if (es != hipSuccess && rc == LDPC_OK) {
+        rc = fail(LDPC_ERR_HIP, "ldpc_decode: draining the streams: %s", hipGetErrorString(es));
+        first_error = g_err;
+    }
+    /* lock mode: the pages go back to the caller; a block that cannot be released stays on record */
+    for (void *p : d->locked_blocks) {
+        const hipError_t eu = registry.unlock(p);
+        if (eu == hipSuccess) continue;
+        d->stuck_blocks.push_back(p);
+        if (rc == LDPC_OK) {
+            rc = fail(LDPC_ERR_HIP, "hipHostUnregister(%p) failed: %s -- the block stays page-locked and on this "
+                      "library's record", p, hipGetErrorString(eu));
+            first_error = g_err;
+        }
+    }
+    d->locked_blocks.clear();
     if (!first_error.empty()) g_err = first_error;
     return rc;
 }
@@ -1580,7 +1593,7 @@ static int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, u
  * K % 8 != 0 a frame's first byte is (frame*K)/8 with the division applied per launch group
  * (MyLdpc.cpp:577-616 passes &srcCode[off*K/8]), so ranges must start where frame*K is a multiple
  * of 8 -- and on a group boundary once the stream is longer than one group. */
-static int32_t shard_unit(const ldpc_decoder_config &cfg, int64_t frames)
+int32_t shard_unit(const ldpc_decoder_config &cfg, int64_t frames)
 {
     if (cfg.K % 8 == 0) return 1;
     int64_t u = 8;
@@ -1593,6 +1606,8 @@ static int32_t shard_unit(const ldpc_decoder_config &cfg, int64_t frames)
     return (int32_t)std::min<int64_t>(u, 0x7fffffff);
 }
 
+}  // namespace
+
 int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t *out_host,
                 int64_t out_bytes, int32_t *iters)
 {
@@ -1601,49 +1616,61 @@ int ldpc_decode(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
     if (frames == 0) return LDPC_OK;
     if (!llr_host || !out_host) return fail(LDPC_ERR_ARG, "llr/out is NULL");
     if (out_bytes < 0) return fail(LDPC_ERR_ARG, "out_bytes < 0");
-    if (d->shards.empty()) return decode_host(d, llr_host, frames, out_host, out_bytes, iters, 0);
+    /* asked once, before any thread touches the buffer */
+    const InputMode mode = resolve_input_mode(d->cfg, llr_host, (size_t)frames * d->N * sizeof(float));
+    if (d->shards.empty()) return decode_host(d, llr_host, frames, out_host, out_bytes, iters, mode);
 
-    /* several devices: one host thread per device decodes a contiguous frame range */
+    /* several devices: each entry's own host thread decodes a contiguous frame range */
     const int n = (int)d->shards.size();
     const int32_t unit = shard_unit(d->cfg, frames);
     std::vector<int64_t> lo((size_t)n), hi((size_t)n);
-    int active = 0;
     for (int i = 0; i < n; ++i) {
         const int rc = ldpc_shard_range(frames, i, n, unit, &lo[i], &hi[i]);
         if (rc) return rc;
-        active += hi[i] > lo[i];
     }
-    /* asked once, before any thread locks anything */
-    (void)active;
-    const int pin_mode = caller_locked_memory(llr_host) ? 2 : 1;
-    std::vector<int> rcs((size_t)n, LDPC_OK);
-    std::vector<std::string> errs((size_t)n);
-    auto work = [&](int i) {
+    std::vector<ldpc::Job> jobs((size_t)n);
+    for (int i = 0; i < n; ++i) {
         ldpc_decoder *sh = d->shards[i];
         sh->have_last = false;
-        if (hi[i] <= lo[i]) return;
+        if (hi[i] <= lo[i]) continue;
         const int64_t base = lo[i] * (int64_t)d->cfg.K / 8;      /* exact: lo is a multiple of the unit */
         const int64_t room = std::max<int64_t>(0, out_bytes - base);
-        rcs[i] = decode_host(sh, llr_host + (size_t)lo[i] * d->N, hi[i] - lo[i], out_host + base,
-                             std::min(room, ldpc_out_bytes(d->cfg.K, hi[i] - lo[i], d->cfg.pack_mode)),
-                             iters ? iters + lo[i] : nullptr, pin_mode);
-        if (rcs[i]) errs[i] = g_err;
-    };
-    std::vector<std::thread> threads;
-    std::vector<int> inline_work;
-    for (int i = 0; i < n; ++i) d->shards[i]->have_last = false;
-    for (int i = 1; i < n; ++i) {
-        if (hi[i] <= lo[i]) continue;
-        try { threads.emplace_back(work, i); }
-        catch (...) { inline_work.push_back(i); }      /* no thread to be had: this range runs on the caller's */
+        const int64_t lo_i = lo[i], cnt = hi[i] - lo[i];
+        const int64_t obytes = std::min(room, ldpc_out_bytes(d->cfg.K, cnt, d->cfg.pack_mode));
+        const int32_t N = d->N;
+        jobs[i].fn = [sh, llr_host, out_host, iters, lo_i, cnt, base, obytes, N, mode]() -> int {
+            return decode_host(sh, llr_host + (size_t)lo_i * N, cnt, out_host + base, obytes,
+                               iters ? iters + lo_i : nullptr, mode);
+        };
+        d->shard_workers[i]->submit(&jobs[i]);
     }
-    work(0);
-    for (int i : inline_work) work(i);
-    for (auto &t : threads) t.join();
-    for (int i = 0; i < n; ++i)
-        if (rcs[i]) { g_err = errs[i]; return rcs[i]; }
+    int rc = LDPC_OK;
+    for (int i = 0; i < n; ++i) {
+        if (hi[i] <= lo[i]) continue;
+        const int r = d->shard_workers[i]->wait(&jobs[i]);     /* all of them, also after a failure */
+        if (r && rc == LDPC_OK) { rc = r; g_err = jobs[i].err; }
+    }
+    if (rc) return rc;
     d->have_last = true;
     d->last_frames = frames;
+    return LDPC_OK;
+}
+
+int ldpc_host_block_plan(uint64_t base, int64_t frames, int32_t N, int32_t max_batch, int64_t group, uint64_t out[6])
+{
+    if (!out) return fail(LDPC_ERR_ARG, "out is NULL");
+    if (frames <= 0 || N <= 0 || max_batch <= 0 || group < 0 || group * (int64_t)max_batch >= frames)
+        return fail(LDPC_ERR_ARG, "block_plan(frames=%lld, N=%d, max_batch=%d, group=%lld)", (long long)frames, N, max_batch,
+                    (long long)group);
+    const ldpc::GroupBlocks g = ldpc::plan_group_blocks((uintptr_t)base, frames, N, max_batch, group);
+    out[0] = g.s0; out[1] = g.s1; out[2] = g.b0; out[3] = g.b1; out[4] = g.body_end; out[5] = g.whole_by_cpu ? 1 : 0;
+    return LDPC_OK;
+}
+
+int ldpc_host_locked_ranges(int64_t *live, int64_t *stale)
+{
+    if (live) *live = (int64_t)ldpc::PageLockRegistry::instance().live_count();
+    if (stale) *stale = (int64_t)ldpc::PageLockRegistry::instance().stale_count();
     return LDPC_OK;
 }
 

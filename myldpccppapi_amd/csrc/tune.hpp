@@ -62,7 +62,7 @@ inline bool tune_valid(const ldpc_decoder_config &c)
     return c.tune_rows_per_wave >= 0 && c.tune_rows_per_wave <= 4096 && c.tune_cols_per_wave >= 0 &&
            c.tune_cols_per_wave <= 4096 && c.tune_link_rows >= -1 && c.tune_link_rows <= 4096 &&
            c.tune_compact >= -1 && c.tune_ldsp_grid >= 0 && c.tune_ldsp_shape >= 0 && c.tune_ldsp_shape < 65536 &&
-           c.streams >= 0 && c.streams <= 8;
+           c.host_input >= 0 && c.host_input <= 2 && c.host_copy_threads >= 0 && c.host_copy_threads <= 16;
 }
 
 }  // namespace ldpc

@@ -1,10 +1,10 @@
 // Round-trip harness in the shape of the reference's only test, Test.cpp:15-118:
 //   payload 'a'+i%26 -> encode -> AWGN (sd = 10^(-snr/20)) -> decode -> ErrNum / ThroughPut.
 // Usage: coder_roundtrip <rate 0..5> <N> <srcBytes> <batch> <snr_dB> <SP|MS|CPU|TDMP|TDMPCL|MSCL|ENC> [seed]
-//                        [--devices 0,0,...] [--streams n] [--dump <prefix>] [--iters n]
+//                        [--devices 0,0,...] [--host-input n] [--dump <prefix>] [--iters n]
 // ENC: encoder only (no GPU): checks H c = 0 for every frame and prints "ParityFail=<n>".
 // --devices: Coder::setDevices (one Coder over several HIP devices; an ordinal may repeat).
-// --streams: Coder::setStreams (frame ranges of a launch group on streams of their own, same device).
+// --host-input: Coder::setHostInput (1 staged through the pinned ring = default, 2 page-lock the caller's pages).
 // --dump: writes <prefix>.prior (encoded bytes), <prefix>.post (channel floats), <prefix>.out (decoded
 //         bytes) so that a test can run the oracle on exactly these inputs.
 // Prints NonZeros= and the reference's fields (sd=, Time=, <MODE>:<seconds>, ErrNum=, ThroughPut=).
@@ -33,11 +33,11 @@ int main(int argc, char **argv)
     const char *mode = argv[6];
     srand(argc > 7 && argv[7][0] != '-' ? atoi(argv[7]) : 1);
     std::vector<int> devices;
-    int streams = 0;
+    int hostInput = 0;
     std::string dump;
     int iters = 0;
     for (int i = 7; i + 1 < argc; ++i) {
-        if (!strcmp(argv[i], "--streams")) streams = atoi(argv[i + 1]);
+        if (!strcmp(argv[i], "--host-input")) hostInput = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "--devices"))
             for (char *tok = strtok(argv[i + 1], ","); tok; tok = strtok(nullptr, ",")) devices.push_back(atoi(tok));
         else if (!strcmp(argv[i], "--dump")) dump = argv[i + 1];
@@ -53,7 +53,7 @@ int main(int argc, char **argv)
     cout << "NonZeros=" << coder.getNonZeros() << endl;
     if (iters > 0) coder.setMaxIterations(iters);
     if (!devices.empty()) coder.setDevices(devices.data(), (int)devices.size());
-    if (streams) coder.setStreams(streams);
+    if (hostInput) coder.setHostInput(hostInput);
     char *srcCode = (char *)malloc(srcLength);
     char *priorCode = (char *)malloc(coder.getPriorCodeLength(srcLength));
     float *postCode = (float *)malloc(sizeof(float) * coder.getPostCodeLength(srcLength));

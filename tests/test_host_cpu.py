@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(built):
     assert declared == set(_lib.EXPORTS)
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.ldpc_abi_version() == 2
+    assert lib.ldpc_abi_version() == 3
 
 
 def test_c_abi_header_compiles_and_links_as_plain_c(built, tmp_path):
@@ -123,7 +123,8 @@ def test_tuning_fields_are_validated_and_no_environment_is_read(built):
     g = L.Graph(rows, cols, 324, 648)
     lib = _lib.load()
     for field, value in (("tune_flags", 3), ("tune_flags", 1 << 30), ("tune_rows_per_wave", -1), ("tune_link_rows", -2),
-                         ("tune_compact", -2), ("tune_ldsp_shape", 1 << 16), ("streams", 9), ("streams", -1)):
+                         ("tune_compact", -2), ("tune_ldsp_shape", 1 << 16), ("host_input", 3), ("host_input", -1),
+                         ("host_copy_threads", 17), ("host_copy_threads", -1)):
         cfg = _lib.DecoderConfig()
         lib.ldpc_decoder_config_init(ctypes.byref(cfg))
         cfg.K, cfg.max_batch = 324, 4
@@ -383,3 +384,40 @@ def test_cpp_coder_encoder_equals_independent_gf2_solve(built, tmp_path):
             if last:
                 break
         assert f >= 2
+
+
+def test_lock_mode_blocks_stay_inside_the_call_and_are_page_disjoint(built):
+    """LDPC_HOST_INPUT_LOCK_PAGES page arithmetic (ldpc_host_block_plan): for every launch
+    group the page-locked block consists of whole pages, lies inside the call's own byte range
+    [base, base + frames*N*4) -- also when a tiny last group shares the previous group's last page,
+    the case that used to round a block UP past the caller's buffer -- blocks of different groups are
+    page-disjoint, and head + body + tail tile the group's bytes exactly."""
+    rng = np.random.default_rng(5)
+    cases = [(0x7f0000001000 + 12, 2049, 648, 2048),          # ADVICE's example: 2592-byte last group
+             (0x7f0000000ff8, 2049, 648, 2048), (0x7f0000000000, 4097, 648, 2048),
+             (0x7f0000000004, 3 * 4096 + 1, 64800, 4096), (0x7f0000000800, 5000, 2304, 1024),
+             (0x7f0000000000, 3, 1, 1), (0x7f0000000ffc, 2, 1024, 1), (0x7f0000000010, 4096, 64800, 4096)]
+    for _ in range(200):
+        cases.append((0x7f0000000000 + int(rng.integers(0, 8192)) * 4, int(rng.integers(1, 6000)),
+                      int(rng.integers(1, 3000)), int(rng.integers(1, 2500))))
+    for base, frames, N, B in cases:
+        end = base + frames * N * 4
+        groups = (frames + B - 1) // B
+        prev_b1, prev_s1 = 0, base
+        for k in range(groups):
+            s0, s1, b0, b1, body_end, whole = L.capi.host_block_plan(base, frames, N, B, k)
+            assert s0 == prev_s1 and s1 == base + min(frames, (k + 1) * B) * N * 4
+            prev_s1 = s1
+            if whole:
+                assert b0 == b1 == 0
+                continue
+            assert b0 % 4096 == 0 and b1 % 4096 == 0 and b0 < b1
+            assert base <= b0 and b1 <= end, (base, frames, N, B, k)          # never past the call's bytes
+            assert s0 <= b0 < s0 + 4096 and b0 <= body_end <= min(b1, s1)
+            assert body_end == min(b1, s1) and s1 - body_end < 4096           # tail shorter than a page
+            assert b0 >= prev_b1                                               # page-disjoint from the group before
+            prev_b1 = b1
+        assert prev_s1 == end
+    with pytest.raises(L.LdpcError):
+        L.capi.host_block_plan(0x1000, 10, 8, 4, 3)                           # group 3 of 3 groups (0..2)
+    assert L.capi.host_locked_ranges() == (0, 0)
