@@ -44,6 +44,7 @@ ITERS = 50
 SIGMA = 0.95
 SEED = 20260101
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4     # G wave64 VALU instructions per second: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles
 
 # Extra measurement points (BASELINE.json configs[3], configs[4]); reported under "extra" of the
 # headline line at N = 1, or alone with   python bench.py --config bg1_layered | dvbs2_910_f16
@@ -101,34 +102,56 @@ def measure_extra(name, steps, warmup, batch=0, sigma=0.0, fpl=0, poll=-1, tune=
     kt = [k for k in dec.kernel_times() if k["phase"] in (0, 1, 2)]
     iters = it.cpu().numpy()
     frame_iters = float(iters.sum())
-    kb = sum(k["bytes_total"] for k in kt)
     kms = sum(k["ms_total"] for k in kt)
     one_launch = len(kt) == 1 and ("ldsp" in kt[0]["name"] or "fused" in kt[0]["name"])
-    hbm_moved = kb
-    if one_launch:
-        # LDS / cache resident decode: the kernel's HBM traffic is the channel values and the packed
-        # bits only; `achieved` stays SURVEY section 8(d)'s algorithmic figure of the schedule
-        # (16 E bytes per frame-iteration) over the kernel's time, so it can exceed the HBM peak
-        kb = bytes_fi * frame_iters * steps
     res = {"metric": "decoded Mbit/s (info bits)", "value": round(B * K / dt / 1e6, 2), "unit": "Mbit/s",
            "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 3),
            "higher_is_better": True, "dtype": "f16" if c["msg"] == "f16" else "f32", "data": "synthetic",
            "config": {"workload": c["desc"], "frames": B, "rounds_launched": st["iterations_launched"],
                       "avg_iterations_per_frame": round(frame_iters / B, 2),
                       "frames_converged": st["frames_converged"],
-                      "bit_errors_in_converged_frames": int(np.unpackbits(out.cpu().numpy().reshape(B, -1)[iters < c["iters"]]).sum())},
-           "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "bytes_per_frame_iteration": bytes_fi,
-                        "message_kernels_achieved": round(kb / (kms * 1e-3) / 1e9, 1),
-                        "message_kernels_frac": round(kb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "whole_step_frac_on_launched_rounds": round(bytes_fi * st["iterations_launched"] * B / dt / 1e9 / HBM_PEAK_GBS, 4),
-                        "per_kernel": {k["name"]: {"avg_ms": round(k["ms_total"] / k["launches"], 4),
-                                                   "GB/s": round(k["bytes_total"] / (k["ms_total"] * 1e-3) / 1e9, 1)}
-                                       for k in sorted(kt, key=lambda k: -k["ms_total"])[:6]}}}
+                      "bit_errors_in_converged_frames": int(np.unpackbits(out.cpu().numpy().reshape(B, -1)[iters < c["iters"]]).sum())}}
     if one_launch:
-        res["roofline"]["note"] = ("one launch, frame state in LDS and check records in L2/Infinity Cache: "
-                                   "achieved = algorithmic bytes of the layered schedule / kernel time, not HBM traffic")
-        res["roofline"]["hbm_bytes_per_launch"] = int(hbm_moved / max(1, kt[0]["launches"]))
+        # LDS / cache resident decode (one launch; frame state in LDS, check records in L2 / Infinity Cache): HBM sees
+        # the channel values in and the packed bits out only, so HBM is not what bounds it.  The kernel is bound by
+        # vector-ALU issue: achieved = VALU wave-instructions per second, peak = CUs x 4 SIMDs x clock / 4 cycles per
+        # wave64 instruction.  The instruction count per frame-iteration comes from the committed PMC profile of this
+        # kernel (SQ_INSTS_VALU over one launch / frames / iterations: the code path per frame-iteration is fixed).
+        prof = {}
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("__valu__", {}).get(name, {})
+        except Exception:
+            pass
+        peak = VALU_PEAK_GINST
+        per_fi = prof.get("valu_wave_insts_per_frame_iteration")
+        ach = None if not per_fi else per_fi * frame_iters * steps / (kms * 1e-3) / 1e9
+        res["roofline"] = {"bound": "valu", "kernel": kt[0]["name"], "unit": "G wave-instructions/s", "peak": peak,
+                           "peak_is": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction",
+                           "achieved": None if ach is None else round(ach, 1),
+                           "frac": None if ach is None else round(ach / peak, 4),
+                           "valu_wave_insts_per_frame_iteration": per_fi, "valu_source": prof.get("source"),
+                           "avg_launch_ms": round(kms / max(1, kt[0]["launches"]), 4),
+                           "edge_updates_per_s_G": round(len(rows) * frame_iters * steps / (kms * 1e-3) / 1e9, 1),
+                           "hbm_side_note": {"bytes_per_launch": int(kt[0]["bytes_total"] / max(1, kt[0]["launches"])),
+                                             "GB/s": round(kt[0]["bytes_total"] / (kms * 1e-3) / 1e9, 1),
+                                             "what": "channel values in + packed bits out: all the HBM traffic of the launch; an "
+                                                     "HBM-streaming formulation of the same schedule would move %d B per "
+                                                     "frame-iteration (16 E)" % bytes_fi}}
+    else:
+        # streaming kernels under early termination: a tile that was finished when a round began leaves at kernel
+        # entry, so a round's traffic is priced at the frames of the tiles that still worked (counted on the device:
+        # stats.frame_rounds), not at frames x rounds launched
+        fr = st["frame_rounds"] * steps
+        kb = bytes_fi * fr
+        res["roofline"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "bytes_per_frame_iteration": bytes_fi, "frame_rounds_worked_per_step": st["frame_rounds"],
+                           "frame_rounds_if_no_tile_skipped": st["iterations_launched"] * B,
+                           "frame_iterations_needed": int(frame_iters),
+                           "achieved": round(kb / (kms * 1e-3) / 1e9, 1),
+                           "frac": round(kb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "whole_step_frac": round(bytes_fi * st["frame_rounds"] / dt / 1e9 / HBM_PEAK_GBS, 4),
+                           "per_kernel_avg_ms": {k["name"]: round(k["ms_total"] / k["launches"], 4)
+                                                 for k in sorted(kt, key=lambda k: -k["ms_total"])[:6]}}
     dec.close()
     del y, out, it
     torch.cuda.empty_cache()

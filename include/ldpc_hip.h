@@ -175,6 +175,10 @@ typedef struct ldpc_decode_stats {
     float ms_other;              /* init / pack / bookkeeping kernels                        */
     int32_t launches_check;      /* kernel launches behind ms_check                          */
     int32_t launches_var;
+    int64_t frame_rounds;        /* streaming flooding kernels: sum over the rounds of the frames in tiles that
+                                    still did work (tile size x tiles with a running frame when the round began;
+                                    finished tiles leave at kernel entry): what a round's traffic is priced at
+                                    under early termination.  0 for the one-launch and layered kernels    */
 } ldpc_decode_stats;
 
 /* ---- library -------------------------------------------------------------- */

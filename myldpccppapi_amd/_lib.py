@@ -43,7 +43,8 @@ class DecodeStats(ctypes.Structure):
                 ("frames", ctypes.c_int64), ("frames_converged", ctypes.c_int64),
                 ("ms_total", ctypes.c_float), ("ms_check", ctypes.c_float),
                 ("ms_var", ctypes.c_float), ("ms_other", ctypes.c_float),
-                ("launches_check", ctypes.c_int32), ("launches_var", ctypes.c_int32)]
+                ("launches_check", ctypes.c_int32), ("launches_var", ctypes.c_int32),
+                ("frame_rounds", ctypes.c_int64)]
 
 
 class KernelTime(ctypes.Structure):

@@ -394,25 +394,29 @@ __device__ __forceinline__ void check_rows(const T *Qt, T *Rt, const int32_t *__
     }
 }
 
-template <int ALGO, int V, typename T, int D, int DLO> struct CheckDispatch {
+template <int ALGO, int V, typename T, int D, int DLO, int W = 1> struct CheckDispatch {
     static __device__ __forceinline__ void run(int deg, const T *Qt, T *Rt, const int32_t *e0s, int rb, int re)
     {
-        if (deg == D) check_rows<ALGO, D, V, 1, T>(Qt, Rt, e0s, rb, re);
-        else CheckDispatch<ALGO, V, T, D - 1, DLO>::run(deg, Qt, Rt, e0s, rb, re);
+        if (deg == D) check_rows<ALGO, D, V, W, T>(Qt, Rt, e0s, rb, re);
+        else CheckDispatch<ALGO, V, T, D - 1, DLO, W>::run(deg, Qt, Rt, e0s, rb, re);
     }
 };
-template <int ALGO, int V, typename T, int DLO> struct CheckDispatch<ALGO, V, T, DLO, DLO> {
+template <int ALGO, int V, typename T, int DLO, int W> struct CheckDispatch<ALGO, V, T, DLO, DLO, W> {
     static __device__ __forceinline__ void run(int, const T *Qt, T *Rt, const int32_t *e0s, int rb, int re)
     {
-        check_rows<ALGO, DLO, V, 1, T>(Qt, Rt, e0s, rb, re);
+        check_rows<ALGO, DLO, V, W, T>(Qt, Rt, e0s, rb, re);
     }
 };
 
-/* narrow waves (1 value per lane), degrees DLO..DHI */
-template <int ALGO, int V, typename T, int DLO, int DHI>
+/* degrees DLO..DHI; W values per lane (V / W consecutive waves cover a row's segment).  W = 1: narrow waves,
+ * the form of all fp32 kernels (256 B per wave-instruction).  fp16 messages at V = 4 use W = 2: with one
+ * 2-byte value per lane a wave-instruction moves 128 B and the degree-30 rows of the rate-9/10 code ran at
+ * 5.0 TB/s against 6.0 for the fp32 narrow form. */
+template <int ALGO, int V, typename T, int DLO, int DHI, int W = 1>
 __global__ __launch_bounds__(kBlock) void check_group_kernel(const CheckArgs a, const GroupClass *__restrict__ cls, int n_classes)
 {
     constexpr size_t F = 64 * V;
+    constexpr int SUB = V / W;
     const int lane = threadIdx.x & 63;
     const GridPos gp = grid_pos(a.tiles_first);
     const int tile = tile_select<V>(a.tail, a.done, gp.row);
@@ -420,13 +424,13 @@ __global__ __launch_bounds__(kBlock) void check_group_kernel(const CheckArgs a, 
     int c = 0;
     while (c + 1 < n_classes && gp.block >= cls[c + 1].block_begin) ++c;
     const int wave = (gp.block - cls[c].block_begin) * kWavesPerBlock + wave_id_in_block();
-    const int sub = wave % V;
-    const int r_begin = (wave / V) * a.rows_per_wave;
+    const int sub = wave % SUB;
+    const int r_begin = (wave / SUB) * a.rows_per_wave;
     const int r_end = min(r_begin + a.rows_per_wave, cls[c].count);
-    const size_t lane_off = (size_t)sub * 64 + (size_t)lane;
+    const size_t lane_off = (size_t)sub * 64 * W + (size_t)lane * W;
     const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + lane_off;
     T *Rt = static_cast<T *>(a.R) + (size_t)tile * (size_t)a.E * F + lane_off;
-    CheckDispatch<ALGO, V, T, DHI, DLO>::run(cls[c].degree, Qt, Rt, cls[c].ids, r_begin, r_end);
+    CheckDispatch<ALGO, V, T, DHI, DLO, W>::run(cls[c].degree, Qt, Rt, cls[c].ids, r_begin, r_end);
 }
 
 /* checkResult, decodeCL.c:88-108, on the bit masks: one thread per row XORs the
@@ -1353,6 +1357,8 @@ struct StateArgs {
     int32_t freeze;                     /* early_term */
     TailRef tail;
     int32_t *__restrict__ running;      /* [max_iter + 2] or nullptr: running[iter] += frames still running */
+    int32_t *__restrict__ tile_rounds;  /* [1] or nullptr: += 1 per tile that still had a running frame when round `iter` began,
+                                           i.e. whose kernels did not leave at entry (what the round's traffic is priced at) */
 };
 
 /* isDones bookkeeping (decodeCL.c:48-49, checkDones :296-300): a frame whose
@@ -1368,6 +1374,7 @@ template <int V> __global__ void state_kernel(const StateArgs a)
     }
     const int lane = threadIdx.x;      /* 64 threads */
     int n_active = 0;
+    bool worked = false;               /* some frame of the tile was running when this round began */
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         const int64_t frame = (int64_t)tile * F + (int64_t)lane * V + v;
@@ -1378,6 +1385,7 @@ template <int V> __global__ void state_kernel(const StateArgs a)
             a.iters[(size_t)tile * F + lane * V + v] = a.max_iter;
         } else {
             const uint64_t old = a.done[(size_t)tile * V + v];
+            worked = worked || old != ~0ull;
             const uint64_t clean = ~a.fail[(size_t)tile * V + v];
             const uint64_t newly = clean & ~old;
             if ((newly >> lane) & 1ull) a.iters[(size_t)tile * F + lane * V + v] = a.iter;
@@ -1388,6 +1396,7 @@ template <int V> __global__ void state_kernel(const StateArgs a)
     }
     if (lane == 0 && n_active && a.active) atomicAdd(a.active, n_active);
     if (lane == 0 && n_active && a.running) atomicAdd(&a.running[a.iter], n_active);
+    if (lane == 0 && worked && a.tile_rounds) atomicAdd(a.tile_rounds, 1);
 }
 
 /* ---- tail compaction (early termination): when only a few frames of a large batch are still
@@ -1427,6 +1436,42 @@ __global__ __launch_bounds__(kBlock) void compact_gather_kernel(const T *__restr
     dst[((size_t)ct * rows + i) * 64 + j] = val;
 }
 
+/* The same gather for MANY frames (hundreds, sitting in every tile of the batch): one thread per element as
+ * above touches a 64-byte sector for every 2- or 4-byte value, i.e. reads the whole array through the L2 in
+ * sector-sized requests.  Here a block takes one row i, streams that row's segments of all `tiles` parent
+ * tiles into LDS with coalesced 16-byte loads, chunk by chunk, and picks the running frames' values from
+ * there.  HBM traffic = one pass over the parent array (a third of a round) however many frames move. */
+constexpr int kGatherChunk = 4096;      /* elements staged at a time (16 KB of fp32) */
+template <int V, typename T>
+__global__ __launch_bounds__(kBlock) void compact_gather_rows_kernel(const T *__restrict__ src, T *__restrict__ dst,
+                                                                     const int32_t *__restrict__ map, int32_t count,
+                                                                     int64_t rows, int32_t tiles)
+{
+    constexpr int F = 64 * V;
+    constexpr int TPC = kGatherChunk / F;               /* parent tiles per chunk */
+    __shared__ __attribute__((aligned(16))) T stage[kGatherChunk];
+    const int64_t i = blockIdx.x;
+    const int cslots = ((count + 63) / 64) * 64;        /* child slots in use (whole child tiles of 64) */
+    for (int t0 = 0; t0 < tiles; t0 += TPC) {
+        const int nt = min(TPC, tiles - t0);
+        /* 16 bytes per lane (a tile's row segment is F * sizeof(T) >= 128 bytes, 16-byte aligned) */
+        constexpr int VEC = 16 / (int)sizeof(T);
+        for (int k = threadIdx.x * VEC; k < nt * F; k += kBlock * VEC)
+            *reinterpret_cast<vf4 *>(&stage[k]) =
+                ld_stream(reinterpret_cast<const vf4 *>(src + ((size_t)(t0 + k / F) * rows + i) * F + (k % F)));
+        __syncthreads();
+        for (int j = threadIdx.x; j < cslots; j += kBlock) {
+            if (j < count) {
+                const int f = map[j] - t0 * F;
+                if (f >= 0 && f < nt * F) dst[((size_t)(j / 64) * rows + i) * 64 + (j % 64)] = stage[f];
+            } else if (t0 == 0) {
+                dst[((size_t)(j / 64) * rows + i) * 64 + (j % 64)] = (T)0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 /* hard bits: child word n = bit j <- parent bit of frame map[j] (gather), and back (scatter; also the
  * iteration counts and the converged flags) */
 template <int V> __global__ __launch_bounds__(kBlock) void compact_hard_kernel(uint64_t *__restrict__ parent, uint64_t *__restrict__ child,
@@ -1449,6 +1494,45 @@ template <int V> __global__ __launch_bounds__(kBlock) void compact_hard_kernel(u
     } else if (jg < count) {
         if ((*cw >> j) & 1ull) atomicOr(word, 1ull << l);
         else atomicAnd(word, ~(1ull << l));
+    }
+}
+
+/* The way back for many frames: one atomic per bit (above) is 44 M device atomics for 681 frames of the
+ * rate-9/10 code.  Instead every parent word is rewritten by ONE thread that looks up, for the bits of its
+ * frames that were handed over, the child's bit: inv[frame] = child slot, moved[(tile, v)] = which bits of
+ * that word moved (both filled by compact_inverse_kernel). */
+template <int V> __global__ void compact_inverse_kernel(const int32_t *__restrict__ map, int32_t count, int32_t *__restrict__ inv,
+                                                        unsigned long long *__restrict__ moved)
+{
+    constexpr int F = 64 * V;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const int f = map[j], fi = f % F;
+    inv[f] = j;
+    atomicOr(&moved[(size_t)(f / F) * V + fi % V], 1ull << (fi / V));
+}
+
+template <int V> __global__ __launch_bounds__(kBlock) void compact_hard_back_kernel(uint64_t *__restrict__ parent, const uint64_t *__restrict__ child,
+                                                                                    const int32_t *__restrict__ inv,
+                                                                                    const unsigned long long *__restrict__ moved, int32_t N)
+{
+    constexpr int F = 64 * V;
+    const int n = blockIdx.x * kBlock + threadIdx.x;
+    const int tile = blockIdx.y;
+    if (n >= N) return;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        uint64_t m = moved[(size_t)tile * V + v];
+        if (!m) continue;
+        uint64_t w = parent[((size_t)tile * N + n) * V + v];
+        while (m) {
+            const int l = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            const int j = inv[tile * F + l * V + v];
+            const uint64_t bit = (child[(size_t)(j / 64) * N + n] >> (j % 64)) & 1ull;
+            w = (w & ~(1ull << l)) | (bit << l);
+        }
+        parent[((size_t)tile * N + n) * V + v] = w;
     }
 }
 

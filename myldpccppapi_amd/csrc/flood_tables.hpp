@@ -30,6 +30,7 @@ struct FloodFns {
     LinkFn link_half[kMaxUnrolledDegree + 1] = {};            /* 2 values per lane (V = 4) */
     VarFn var[kMaxUnrolledDegree + 1] = {};
     CheckGroupFn check_group[kCheckBuckets] = {};
+    int check_group_width = 1;                                /* values per lane of the group check kernels */
     VarGroupFn var_group[kVarBuckets] = {};
     InitFn init = nullptr;
     int max_check_unrolled = kMaxUnrolledDegree;

@@ -65,8 +65,11 @@ template <int ALGO, int V, typename T> void fill_v(FloodFns *f)
     constexpr int DM = kMaxUnrolledDegree;
     FloodTable<ALGO, V, T, DM>::fill(f->check, f->check_wide, f->var);
     LinkTable<ALGO, V, T, DM>::fill(f->link, f->link_narrow, f->link_deep, f->link_half);
-    f->check_group[0] = check_group_kernel<ALGO, V, T, 1, 8>;
-    f->check_group[1] = check_group_kernel<ALGO, V, T, 9, 16>;
+    /* fp16 messages in tiles of 256 frames: two values per lane (flood_kernels.hpp: check_group_kernel) */
+    constexpr int GW = (sizeof(T) == 2 && V == 4) ? 2 : 1;
+    f->check_group_width = GW;
+    f->check_group[0] = check_group_kernel<ALGO, V, T, 1, 8, GW>;
+    f->check_group[1] = check_group_kernel<ALGO, V, T, 9, 16, GW>;
     f->check_group[2] = f->check_group[3] = nullptr;
     f->var_group[0] = var_group_kernel<ALGO, V, T, 1, 4>;
     f->var_group[1] = var_group_kernel<ALGO, V, T, 5, 8>;
@@ -75,8 +78,8 @@ template <int ALGO, int V, typename T> void fill_v(FloodFns *f)
     f->max_check_unrolled = DM;
     if (ALGO == kAlgoMS) {       /* min-sum rows of degree 17..32: narrow unrolled kernels */
         CheckTableMS<V, T, kMaxUnrolledCheckDegreeMS>::fill(f->check, f->check_wide);
-        f->check_group[2] = check_group_kernel<kAlgoMS, V, T, 17, 24>;
-        f->check_group[3] = check_group_kernel<kAlgoMS, V, T, 25, 32>;
+        f->check_group[2] = check_group_kernel<kAlgoMS, V, T, 17, 24, GW>;
+        f->check_group[3] = check_group_kernel<kAlgoMS, V, T, 25, 32, GW>;
         f->max_check_unrolled = kMaxUnrolledCheckDegreeMS;
     }
 }

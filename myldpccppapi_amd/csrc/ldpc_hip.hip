@@ -193,6 +193,7 @@ struct ldpc_decoder {
     std::vector<ClassGroup> check_groups, var_groups;
     std::vector<int> check_solo, var_solo;
     CheckGroupFn check_group_fn[kCheckBuckets] = {};
+    int check_group_width = 1;          /* values per lane of the group check kernels (2 for fp16 messages at V = 4) */
     VarGroupFn var_group_fn[kVarBuckets] = {};
     DevBuf<int32_t> extra_e0, extra_deg;
     int n_extra = 0;
@@ -256,7 +257,10 @@ struct ldpc_decoder {
     /* tail compaction (flood_kernels.hpp): a V = 1, one-tile decoder that takes over the last running
      * frames of a polled, early-terminating decode */
     ldpc_decoder *child = nullptr;
-    DevBuf<int32_t> cmap;               /* [kCompactCapacity] frame indices handed to the child */
+    DevBuf<int32_t> cmap;               /* [child_capacity] frame indices handed to the child */
+    DevBuf<int32_t> cinv;               /* [max_batch] child slot of a handed-over frame (valid where cmoved says so) */
+    DevBuf<unsigned long long> cmoved;  /* [T][V] bits of each mask word whose frames were handed over */
+    int child_capacity = ldpc::kCompactCapacity;      /* frames the child holds: 512, or 1024 for batches of >= 4096 frames */
     int compact_threshold = ldpc::kCompactCapacity;   /* cfg.tune_compact: 0 = off, else hand over when <= this many frames run */
     bool is_child = false;
     /* device-side tail (flood_kernels.hpp: TailRef, tail_gather_kernel): TO overflow tiles follow the T
@@ -289,7 +293,9 @@ struct ldpc_decoder {
     int tune_check_wide = 0;            /* 1: check kernels move V floats per lane */
     int32_t last_iterations = 0;
     int64_t last_frames = 0;
-    DevBuf<int32_t> summary;            /* [2]: max iters, converged count */
+    DevBuf<int32_t> summary;            /* [4]: max iters, converged count, tile-rounds that did work (early termination) */
+    bool child_ran = false;             /* the tail-compaction child took part in the last call */
+    int32_t last_tiles = 0;
 
     /* a handle over several devices (ldpc_decoder_create_multi): one single-device decoder per entry
      * of the device list, and one persistent host thread per entry that runs its frame range; this
@@ -410,15 +416,28 @@ template <int V> int compact_and_finish(ldpc_decoder *d, int64_t frames, int cou
     const unsigned ct = (unsigned)((count + 63) / 64);      /* child tiles in use */
     HIP_TRY(hipMemsetAsync(d->active.p, 0, sizeof(int32_t), s));
     compact_list_kernel<V><<<(unsigned)((frames + kBlock - 1) / kBlock), kBlock, 0, s>>>(d->done.p, frames, d->cmap.p,
-                                                                                         d->active.p, kCompactCapacity);
+                                                                                         d->active.p, d->child_capacity);
     const dim3 ge((unsigned)((d->E + kWavesPerBlock - 1) / kWavesPerBlock), ct);
     const dim3 gn((unsigned)((d->N + kWavesPerBlock - 1) / kWavesPerBlock), ct);
+    /* many frames: one coalesced pass over the parent's rows through LDS; few: one sector per value */
+    const bool rowwise = count >= 128;
+    const int ptiles = (int)((frames + 64 * V - 1) / (64 * V));
     if (d->msg_size == 2) {
-        compact_gather_kernel<V, _Float16><<<ge, kBlock, 0, s>>>((const _Float16 *)d->Q.p, (_Float16 *)c->Q.p, d->cmap.p, count, d->E);
-        compact_gather_kernel<V, _Float16><<<gn, kBlock, 0, s>>>((const _Float16 *)d->chan.p, (_Float16 *)c->chan.p, d->cmap.p, count, d->N);
+        if (rowwise) {
+            compact_gather_rows_kernel<V, _Float16><<<(unsigned)d->E, kBlock, 0, s>>>((const _Float16 *)d->Q.p, (_Float16 *)c->Q.p, d->cmap.p, count, d->E, ptiles);
+            compact_gather_rows_kernel<V, _Float16><<<(unsigned)d->N, kBlock, 0, s>>>((const _Float16 *)d->chan.p, (_Float16 *)c->chan.p, d->cmap.p, count, d->N, ptiles);
+        } else {
+            compact_gather_kernel<V, _Float16><<<ge, kBlock, 0, s>>>((const _Float16 *)d->Q.p, (_Float16 *)c->Q.p, d->cmap.p, count, d->E);
+            compact_gather_kernel<V, _Float16><<<gn, kBlock, 0, s>>>((const _Float16 *)d->chan.p, (_Float16 *)c->chan.p, d->cmap.p, count, d->N);
+        }
     } else {
-        compact_gather_kernel<V, float><<<ge, kBlock, 0, s>>>((const float *)d->Q.p, (float *)c->Q.p, d->cmap.p, count, d->E);
-        compact_gather_kernel<V, float><<<gn, kBlock, 0, s>>>((const float *)d->chan.p, (float *)c->chan.p, d->cmap.p, count, d->N);
+        if (rowwise) {
+            compact_gather_rows_kernel<V, float><<<(unsigned)d->E, kBlock, 0, s>>>((const float *)d->Q.p, (float *)c->Q.p, d->cmap.p, count, d->E, ptiles);
+            compact_gather_rows_kernel<V, float><<<(unsigned)d->N, kBlock, 0, s>>>((const float *)d->chan.p, (float *)c->chan.p, d->cmap.p, count, d->N, ptiles);
+        } else {
+            compact_gather_kernel<V, float><<<ge, kBlock, 0, s>>>((const float *)d->Q.p, (float *)c->Q.p, d->cmap.p, count, d->E);
+            compact_gather_kernel<V, float><<<gn, kBlock, 0, s>>>((const float *)d->chan.p, (float *)c->chan.p, d->cmap.p, count, d->N);
+        }
     }
     compact_hard_kernel<V><<<gn, kBlock, 0, s>>>(d->hard.p, c->hard.p, d->cmap.p, count, d->N, 0);
     compact_child_state_kernel<0><<<ct, 64, 0, s>>>(c->done.p, c->iters.p, count, d->cfg.max_iter);
@@ -427,7 +446,15 @@ template <int V> int compact_and_finish(ldpc_decoder *d, int64_t frames, int cou
     c->tap_iter = 0;
     const int rc = run_flooding<1>(c, nullptr, count, nullptr, 0, nullptr, s, it + 1);
     if (rc) return rc;
-    compact_hard_kernel<V><<<gn, kBlock, 0, s>>>(d->hard.p, c->hard.p, d->cmap.p, count, d->N, 1);
+    d->child_ran = true;
+    if (rowwise) {
+        HIP_TRY(hipMemsetAsync(d->cmoved.p, 0, d->cmoved.n * sizeof(unsigned long long), s));
+        compact_inverse_kernel<V><<<(unsigned)((count + 255) / 256), 256, 0, s>>>(d->cmap.p, count, d->cinv.p, d->cmoved.p);
+        compact_hard_back_kernel<V><<<dim3((unsigned)((d->N + kBlock - 1) / kBlock), (unsigned)ptiles), kBlock, 0, s>>>(
+            d->hard.p, c->hard.p, d->cinv.p, d->cmoved.p, d->N);
+    } else {
+        compact_hard_kernel<V><<<gn, kBlock, 0, s>>>(d->hard.p, c->hard.p, d->cmap.p, count, d->N, 1);
+    }
     compact_finish_kernel<V><<<ct, 64, 0, s>>>(d->done.p, d->iters.p, c->done.p, c->iters.p, d->cmap.p, count);
     HIP_TRY(hipGetLastError());
     return LDPC_OK;
@@ -448,7 +475,8 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
 
     const bool resume = start_round > 1;    /* a child taking over running frames: their state is in place */
     HIP_TRY(hipMemsetAsync(d->failw.p, 0, d->failw.n * sizeof(uint64_t), s));
-    HIP_TRY(hipMemsetAsync(d->summary.p, 0, 2 * sizeof(int32_t), s));
+    HIP_TRY(hipMemsetAsync(d->summary.p, 0, 4 * sizeof(int32_t), s));
+    d->child_ran = false;
     /* idle hint from the previous call (asynchronous early termination only) */
     if (!resume && d->summary_pending) {
         if (hipEventQuery(d->ev_summary) == hipSuccess) {
@@ -484,6 +512,10 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
     }
 
     int launched = start_round - 1;
+    /* host polling: every poll_interval rounds -- and every round once a poll has seen a tenth of the frames
+     * finished: from there on the running count falls fast (rate 9/10 at 4096 frames: 4096, 3501, 681, 41
+     * frames take part in rounds 4..7), and the round after which a quarter is left is the one to hand over at */
+    bool poll_dense = false;
     for (int it = start_round; it <= rounds; ++it) {
         const bool fat = idle_after > 0 && it > idle_after;      /* probably idle: fewer, fatter workgroups */
         /* check_i: R_i = check(Q_{i-1}) */
@@ -569,9 +601,10 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
                             d->tune_syn_xcd ? tiles : 0, rbk, tr};
             dim3 sgrid = d->tune_syn_xcd ? dim3(8 * rbk * ((tiles + 7) / 8)) : dim3(rbk, tiles);
             syndrome_kernel<V><<<sgrid, kBlock, 0, s>>>(sa);
-            StateArgs st{d->done.p, fw, d->iters.p, nullptr, frames, it, max_iter, 1, tr, use_tail ? d->running.p : nullptr};
+            StateArgs st{d->done.p, fw, d->iters.p, nullptr, frames, it, max_iter, 1, tr, use_tail ? d->running.p : nullptr,
+                         d->summary.p + 2};
             const bool poll = freeze && it < rounds && d->cfg.poll_interval > 0 && !d->suppress_poll &&
-                              (it % d->cfg.poll_interval) == 0;
+                              ((it % d->cfg.poll_interval) == 0 || poll_dense);
             if (poll) {
                 HIP_TRY(hipMemsetAsync(d->active.p, 0, sizeof(int32_t), s));
                 st.active = d->active.p;
@@ -592,6 +625,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
                 HIP_TRY(hipStreamSynchronize(s));
                 const int running = *d->h_active;
                 if (running == 0) break;        /* every frame frozen: MyLdpc.cpp:1035-1036 */
+                if ((int64_t)running * 10 <= frames * 9 && d->child && tiles > 1) poll_dense = true;
                 if (d->child && running <= d->compact_threshold && (int64_t)running * 4 <= frames && tiles > 1 && !d->tap_iter) {
                     const int rc = compact_and_finish<V>(d, frames, running, it, s);
                     if (rc) return rc;
@@ -602,6 +636,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
         }
     }
     d->last_iterations = launched;
+    d->last_tiles = tiles;
     if (resume) return LDPC_OK;             /* the parent packs */
 
     HIP_TRY(span_begin(d, s, 3));
@@ -777,7 +812,7 @@ int plan_launches(ldpc_decoder *d)
                 gc.degree = cc.degree; gc.count = cc.count; gc.ids = cc.col.p; gc.edges = cc.edge.p;
             }
             auto blocks_of = [&](int per_wave) {
-                const int waves = ((gc.count + per_wave - 1) / per_wave) * (rows ? V : 1);
+                const int waves = ((gc.count + per_wave - 1) / per_wave) * (rows ? V / d->check_group_width : 1);
                 return (waves + ldpc::kWavesPerBlock - 1) / ldpc::kWavesPerBlock;
             };
             gc.block_begin = g.blocks;
@@ -818,6 +853,7 @@ int setup_flooding(ldpc_decoder *d, const ldpc_graph *g, size_t TF)
     memcpy(d->link_half_fn, fns.link_half, sizeof fns.link_half);
     memcpy(d->var_fn, fns.var, sizeof fns.var);
     memcpy(d->check_group_fn, fns.check_group, sizeof fns.check_group);
+    d->check_group_width = fns.check_group_width;
     memcpy(d->var_group_fn, fns.var_group, sizeof fns.var_group);
     d->init_fn = fns.init;
     d->max_check_unrolled = fns.max_check_unrolled;
@@ -1070,7 +1106,7 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
     HIP_TRY(d->done.alloc((size_t)d->TA * d->V));
     HIP_TRY(d->iters.alloc(TF));
     HIP_TRY(d->active.alloc(1));
-    HIP_TRY(d->summary.alloc(2));
+    HIP_TRY(d->summary.alloc(4));
 
     if (cfg->algo == LDPC_ALGO_MS_FUSED) {
         if (cfg->pack_mode != LDPC_PACK_BYTES && cfg->K % 8)
@@ -1164,10 +1200,15 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
             }
             /* tail compaction: with host polling on, the last <= 512 running frames of a batch of several
              * tiles are finished by a small (8 x 64 frames) child decoder (cfg.tune_compact = -1: off, n: threshold) */
-            if (tune.compact) d->compact_threshold = tune.compact < 0 ? 0 : std::min(ldpc::kCompactCapacity, tune.compact);
+            /* the child takes over once at most a quarter of the batch still runs: 1024 frames for the 4096-frame
+             * batches of the benchmark configurations (rate 9/10, fp16: 681 frames still run after round 5 of 8 and
+             * sit in all 16 tiles; a 512-frame child had to wait for round 6), 512 otherwise */
+            d->child_capacity = cfg->max_batch >= 4096 ? 2 * ldpc::kCompactCapacity : ldpc::kCompactCapacity;
+            d->compact_threshold = d->child_capacity;
+            if (tune.compact) d->compact_threshold = tune.compact < 0 ? 0 : std::min(d->child_capacity, tune.compact);
             if (cfg->early_term && cfg->poll_interval > 0 && d->T > 1 && d->compact_threshold > 0 && !t_creating_child) {
                 ldpc_decoder_config cc = *cfg;
-                cc.max_batch = ldpc::kCompactCapacity;
+                cc.max_batch = d->child_capacity;
                 cc.frames_per_lane = 1;
                 cc.layer_rows = 0;                 /* streaming kernels, same arithmetic */
                 cc.tune_compact = -1;
@@ -1177,7 +1218,9 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
                 if (rc) return rc;
                 d->child->is_child = true;
                 HIP_TRY(hipSetDevice(cfg->device));
-                HIP_TRY(d->cmap.alloc(ldpc::kCompactCapacity));
+                HIP_TRY(d->cmap.alloc((size_t)d->child_capacity));
+                HIP_TRY(d->cinv.alloc((size_t)d->T * d->F));
+                HIP_TRY(d->cmoved.alloc((size_t)d->T * d->V));
             }
         }
     }
@@ -1715,6 +1758,7 @@ int ldpc_decoder_stats(ldpc_decoder *d, ldpc_decode_stats *st)
             st->ms_total = std::max(st->ms_total, one.ms_total);
             st->ms_check += one.ms_check; st->ms_var += one.ms_var; st->ms_other += one.ms_other;
             st->launches_check += one.launches_check; st->launches_var += one.launches_var;
+            st->frame_rounds += one.frame_rounds;
         }
         return LDPC_OK;
     }
@@ -1723,10 +1767,23 @@ int ldpc_decoder_stats(ldpc_decoder *d, ldpc_decode_stats *st)
     st->iterations_launched = d->last_iterations;
     st->frames = d->last_frames;
     HIP_TRY(hipEventElapsedTime(&st->ms_total, d->ev_begin, d->ev_end));
-    int32_t summary[2] = {0, 0};
+    int32_t summary[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(summary, d->summary.p, sizeof summary, hipMemcpyDeviceToHost));
     st->batch_time = summary[0];
     st->frames_converged = summary[1];
+    /* frame-rounds the message kernels really worked on (tiles that were finished when a round began leave
+     * at kernel entry): counted on the device with early termination, all launched rounds without; the
+     * one-launch kernels (frames leave individually inside the launch) report 0 */
+    st->frame_rounds = 0;
+    if (!d->use_fused && d->cfg.algo != LDPC_ALGO_LAYERED && d->cfg.algo != LDPC_ALGO_LAYERED_HOST) {
+        st->frame_rounds = d->cfg.early_term ? (int64_t)summary[2] * d->F
+                                             : (int64_t)d->last_iterations * d->last_tiles * d->F;
+        if (d->child && d->child_ran) {
+            int32_t cs[4] = {0, 0, 0, 0};
+            HIP_TRY(hipMemcpy(cs, d->child->summary.p, sizeof cs, hipMemcpyDeviceToHost));
+            st->frame_rounds += (int64_t)cs[2] * d->child->F;
+        }
+    }
     for (size_t i = 0; i < d->spans_used; ++i) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, d->spans[i].a, d->spans[i].b));

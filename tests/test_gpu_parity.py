@@ -236,6 +236,42 @@ def test_k_not_byte_aligned_and_bit_packing(built, algo):
         dec.close()
 
 
+def test_configs0_as_written_one_frame_20_iterations_decodecpu_packing(built, tmp_path):
+    """BASELINE.json configs[0] as written: the (648, 324) rate-1/2 code, batch = 1, 20 iterations, the
+    reference's CPU decoder (`DecodeCPU`, MyLdpc.cpp:684-784: min-sum, bit-offset packing).  Through the C ABI
+    (every kernel choice a one-frame decoder can make) and through the C++ class's DecodeCPU mode, against
+    the oracle's restatement of decodeCPU; one frame at a time over a few noise levels, incl. one that does
+    not converge in 20 iterations."""
+    g, og, K, M, z = _graph(codes.RATE_1_2, 648)
+    for sigma, seed in ((0.6, 1), (0.75, 2), (0.82, 3), (1.1, 4)):
+        y = channel.awgn_frames(648, 0, 1, sigma, seed=seed)
+        want = oracle.decode(og, y, "ms", max_iter=20, pack_mode=1)
+        assert want["out"].size == 41                                  # (1 * 324 + 7) // 8 bytes
+        for tune in (None, kernel_choice("1"), kernel_choice("ldsp"), kernel_choice("0")):
+            dec = L.Decoder(g, K, max_batch=1, algo="ms", max_iter=20, layer_rows=z, pack_mode=L.PACK_BITS, tune=tune)
+            out, iters = dec.decode(y)
+            assert np.array_equal(out, want["out"]) and np.array_equal(iters, want["iters"]), (sigma, tune)
+            assert dec.stats()["batch_time"] == int(want["iters"][0])
+            dec.close()
+    assert want["iters"][0] == 20                                      # the last point ran all 20 iterations
+    # the class: Coder(324, 648, rate_1_2), one frame, setMaxIterations(20), DecodeCPU; its own encoder and test
+    # channel (libc rand), dumped so that the oracle decodes exactly the floats the class decoded
+    exe = str(tmp_path / "coder_roundtrip")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "coder_roundtrip.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "myldpccppapi_amd"), "-lmyldpc", "-lldpc_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "myldpccppapi_amd")])
+    pre = str(tmp_path / "c0")
+    p = subprocess.run([exe, "0", "648", "40", "1", "2.5", "CPU", "5", "--iters", "20", "--dump", pre],
+                       capture_output=True, text=True)
+    assert p.returncode == 0 and "ParityFail=0" in p.stdout, p.stdout + p.stderr
+    post = np.fromfile(pre + ".post", np.float32).reshape(1, 648)
+    o = oracle.decode(og, post, "ms", max_iter=20, pack_mode=1)
+    got = np.fromfile(pre + ".out", np.uint8)
+    assert np.array_equal(got, o["out"][:40])                          # srcLength = 40 bytes are written
+    assert ("Time=%d" % int(o["iters"][0])) in p.stdout
+
+
 @pytest.mark.parametrize("algo", ["ms", "sp", "layered", "ms_fused"])
 def test_degenerate_channel_values(built, algo):
     """Erasures (y = 0), huge values (exp overflows to inf -> inf/inf = NaN in the SP priors),
