@@ -455,6 +455,7 @@ def main():
 
     st = dec.stats()
     kt = dec.kernel_times()
+    link_form = dec.link_form()          # which form of the column-fused check kernel the creation-time timing picked
     assert st["iterations_launched"] == ITERS
     launch_frames = B
     flood = [k for k in kt if k["phase"] in (0, 1)]
@@ -467,7 +468,7 @@ def main():
     except Exception:
         probe = probe_default = probe_nt = None
     mine = {"rank": rank, "device": local_rank, "ms_per_step": round(dt_own / args.steps * 1e3, 3),
-            "kernel": dom["name"], "avg_launch_ms": round(dom["ms_total"] / dom["launches"], 4),
+            "kernel": dom["name"], "kernel_form": None if not link_form else link_form["form"], "avg_launch_ms": round(dom["ms_total"] / dom["launches"], 4),
             "hbm_probe_gbs": None if probe is None else round(probe, 1)}
     per_rank = [mine]
     if world > 1:
@@ -495,8 +496,10 @@ def main():
                 per = tj.get(dom["name"])
                 if per is not None and tc.get("frames_per_gpu"):
                     traffic = int(per * launch_frames / tc["frames_per_gpu"])         # linear in the frames of a launch
-                    traffic_note = ("PMC FETCH_SIZE x2 + WRITE_SIZE per launch from %s (rocprofv3, separate passes, "
-                                    "%d frames per launch%s)" % (tc.get("source", "profiles/"), tc["frames_per_gpu"],
+                    fcal = (tc.get("fetch_calibration") or {}).get("fetch_factor")
+                    traffic_note = ("PMC FETCH_SIZE x %s + WRITE_SIZE per launch from %s (rocprofv3, separate passes, "
+                                    "%d frames per launch%s)" % ("%.3f (calibrated on the run's copy probe)" % fcal if fcal else "2",
+                                                                 tc.get("source", "profiles/"), tc["frames_per_gpu"],
                                                                  "" if tc["frames_per_gpu"] == launch_frames else ", scaled to %d" % launch_frames))
             except Exception:
                 traffic = None
@@ -532,7 +535,7 @@ def main():
                       # copy rate its GPU delivered right after the timed steps
                       "per_rank": per_rank},
             "roofline": {
-                "bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": dom["name"], "kernel_form": link_form, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_note,
                 "avg_launch_ms": round(dom_avg_ms, 4), "launches": dom["launches"],

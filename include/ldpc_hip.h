@@ -266,6 +266,12 @@ typedef struct ldpc_kernel_time {
 int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t capacity,
                               int32_t *count);
 
+/* Which form of the column-fused check kernel this decoder runs (0 wide: V values per lane, 1 narrow: one,
+ * 2 half: two) and, if it was chosen by the creation-time measurement, what each candidate took per launch
+ * on the decoder's own arrays (ms[0..2] in that order, 0 = not a candidate / not measured; *calibrated = 0 when
+ * the form was fixed by the tuning fields or the code has no column-fused rows). */
+int ldpc_decoder_link_form(ldpc_decoder *d, int32_t *form, int32_t *calibrated, float ms[3]);
+
 /* ---- debug taps (tolerance checks against the oracle) ------------------------
  * Stop the NEXT decode call after `iter` check/variable rounds (0 = off) and keep
  * its messages.  ldpc_decoder_dump then copies them out in the reference's layout

@@ -61,7 +61,7 @@ EXPORTS = (
     "ldpc_decoder_create_multi", "ldpc_shard_range", "ldpc_decoder_destroy", "ldpc_decode", "ldpc_decode_device", "ldpc_out_bytes",
     "ldpc_decoder_set_timing", "ldpc_decoder_stats", "ldpc_decoder_kernel_times", "ldpc_decoder_set_tap",
     "ldpc_decoder_dump", "ldpc_awgn_device", "ldpc_count_errors_device", "ldpc_hbm_probe_device", "ldpc_hbm_sustained_device",
-    "ldpc_host_block_plan", "ldpc_host_locked_ranges",
+    "ldpc_host_block_plan", "ldpc_host_locked_ranges", "ldpc_decoder_link_form",
 )
 
 
@@ -117,6 +117,7 @@ def load():
     L.ldpc_host_block_plan.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                        ctypes.POINTER(ctypes.c_uint64)]
     L.ldpc_host_locked_ranges.argtypes = [i64p, i64p]
+    L.ldpc_decoder_link_form.argtypes = [vp, i32p, i32p, ctypes.POINTER(ctypes.c_float)]
     _lib = L
     return L
 

@@ -222,6 +222,16 @@ class Decoder:
                      bytes_moved=arr[i].bytes_moved)
                 for i in range(n.value)]
 
+    def link_form(self):
+        """Form of the column-fused check kernel (None: the code has none) and the creation-time measurement."""
+        form, cal = ctypes.c_int32(-1), ctypes.c_int32(0)
+        ms = (ctypes.c_float * 3)()
+        _lib.check(_lib.load().ldpc_decoder_link_form(self._h, ctypes.byref(form), ctypes.byref(cal), ms))
+        if form.value < 0:
+            return None
+        return {"form": ("wide", "narrow", "half")[form.value], "chosen_by_measurement": bool(cal.value),
+                "ms_per_launch": {"wide": round(ms[0], 4), "narrow": round(ms[1], 4), "half": round(ms[2], 4)}}
+
     def set_tap(self, it):
         _lib.check(_lib.load().ldpc_decoder_set_tap(self._h, int(it)))
 

@@ -1845,6 +1845,18 @@ int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t ca
     return LDPC_OK;
 }
 
+int ldpc_decoder_link_form(ldpc_decoder *d, int32_t *form, int32_t *calibrated, float ms[3])
+{
+    if (!d) return fail(LDPC_ERR_ARG, "decoder is NULL");
+    if (!d->shards.empty()) return ldpc_decoder_link_form(d->shards[0], form, calibrated, ms);
+    bool linked = false;
+    for (auto &rc : d->row_classes) linked = linked || rc.linked;
+    if (form) *form = linked ? d->tune_link_narrow : -1;
+    if (calibrated) *calibrated = d->link_calibrated ? 1 : 0;
+    if (ms) for (int k = 0; k < 3; ++k) ms[k] = d->link_calibrated && d->link_cal_ms[k] < 1e29f ? d->link_cal_ms[k] : 0.0f;
+    return LDPC_OK;
+}
+
 int ldpc_decoder_set_tap(ldpc_decoder *d, int32_t iter)
 {
     if (!d) return fail(LDPC_ERR_ARG, "decoder is NULL");

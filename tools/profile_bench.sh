@@ -5,7 +5,7 @@
 #   3. --pmc WRITE_SIZE  (own pass)    -> HBM write side
 # Outputs under gpurun_out/prof_$1/ ; summaries are copied to profiles/ by tools/summarize_profile.py
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT

@@ -4,10 +4,12 @@ small committed files under profiles/:
   <tag>_kernel_stats.csv   per-kernel calls / total / average / min / max (from --kernel-trace --stats)
   <tag>_pmc_traffic.json   per-kernel FETCH_SIZE / WRITE_SIZE averages per launch (separate --pmc passes)
                            and the HBM bytes they imply, corrected as MI355X_MICROARCH.md (HBM section)
-                           prescribes: counters are in KiB; FETCH_SIZE reports exactly 1/2 of the bytes
-                           of a wide (16 B/lane) coalesced streaming read on gfx950 -> doubled for the
-                           message kernels (also calibrated for the 4 B/lane narrow check kernels, see
-                           below); WRITE_SIZE is exact.
+                           prescribes: counters are in KiB; FETCH_SIZE under-reports coalesced reads on
+                           gfx950 (128-byte requests counted as 64 bytes).  The factor is CALIBRATED in the
+                           same run, not assumed: bench.py's copy probe (hbm_probe_copy_kernel, both cache
+                           policies) reads exactly `probe_bytes` per launch, so factor = known / counted; it
+                           is applied to every kernel and recorded with the kernel's row, next to the
+                           write side's own check (known / counted, expected 1).
   traffic.json             {kernel display name: corrected HBM bytes per launch} read by bench.py
 usage: tools/summarize_profile.py <tag>"""
 import csv, glob, json, os, re, sys
@@ -79,17 +81,27 @@ for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         pmc.setdefault(k, {})[counter + "_KiB_per_launch"] = tot / n
         pmc[k]["launches_" + counter] = n
 traffic = {}
+# calibration from the in-run copy probe: bench.py copies PROBE_BYTES per launch (read) and writes as many
+PROBE_BYTES = float(1 << 30)
+cal = {"fetch_factor": None, "write_factor": None, "probe_rows": {}}
+ff, wf = [], []
+for k, v in pmc.items():
+    if k.startswith("hbm_probe_copy_kernel") and "FETCH_SIZE_KiB_per_launch" in v and "WRITE_SIZE_KiB_per_launch" in v:
+        f = PROBE_BYTES / (v["FETCH_SIZE_KiB_per_launch"] * 1024)
+        w = PROBE_BYTES / (v["WRITE_SIZE_KiB_per_launch"] * 1024)
+        cal["probe_rows"][k] = {"known_bytes_read": PROBE_BYTES, "fetch_factor": f, "write_factor": w}
+        ff.append(f)
+        wf.append(w)
+if ff:
+    cal["fetch_factor"] = sum(ff) / len(ff)
+    cal["write_factor"] = sum(wf) / len(wf)
+fetch_factor = cal["fetch_factor"] if cal["fetch_factor"] else 2.0          # the guide's figure when no probe ran
 for k, v in pmc.items():
     if "FETCH_SIZE_KiB_per_launch" in v and "WRITE_SIZE_KiB_per_launch" in v:
-        # FETCH_SIZE x2 on gfx950: prescribed by the guide for 16 B/lane streams (var/layer kernels
-        # at V = 4) and calibrated here for the narrow check kernels (4 B/lane, 256 B per
-        # wave-instruction): every Q byte is read exactly once (no reuse is possible), the
-        # algorithmic read volume is 3.716 GB per launch and the raw counter shows 1.859 GB,
-        # i.e. exactly 1/2 as well.
-        wide = bool(re.search(r"^(var_kernel|var_group_kernel|layer_kernel|check_kernel|check_group_kernel|check_link_kernel|check_link_narrow_kernel)<", k))
-        fetch = v["FETCH_SIZE_KiB_per_launch"] * 1024 * (2 if wide else 1)
+        fetch = v["FETCH_SIZE_KiB_per_launch"] * 1024 * fetch_factor
         write = v["WRITE_SIZE_KiB_per_launch"] * 1024
-        v["fetch_correction"] = 2 if wide else 1
+        v["fetch_correction"] = round(fetch_factor, 4)
+        v["fetch_correction_source"] = "copy probe of the same run" if cal["fetch_factor"] else "MI355X_MICROARCH.md (no probe in this run)"
         v["hbm_bytes_per_launch"] = fetch + write
         traffic[display(k)] = int(fetch + write)
 if pmc:
@@ -100,8 +112,18 @@ if pmc:
         cfg["frames_per_gpu"] = json.loads(line)["config"]["frames_per_gpu"]
     except Exception:
         cfg["frames_per_gpu"] = 4096
+    cfg["fetch_calibration"] = cal
     traffic["__config__"] = cfg
+    try:        # keep the sections other tools wrote (VALU counts of the record kernel: tools/profile_ldsp.sh)
+        prev = json.load(open(os.path.join(dst, "traffic.json")))
+        for key in prev:
+            if key.startswith("__") and key != "__config__":
+                traffic[key] = prev[key]
+    except Exception:
+        pass
+    pmc["__calibration__"] = cal
     json.dump(pmc, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1, sort_keys=True)
 for k in sorted(pmc):
     print(k, pmc[k])
+print('calibration', cal)
