@@ -421,3 +421,17 @@ def test_lock_mode_blocks_stay_inside_the_call_and_are_page_disjoint(built):
     with pytest.raises(L.LdpcError):
         L.capi.host_block_plan(0x1000, 10, 8, 4, 3)                           # group 3 of 3 groups (0..2)
     assert L.capi.host_locked_ranges() == (0, 0)
+
+
+def test_worker_threads_and_lock_registry_unit(built, tmp_path):
+    """csrc/host_stage.hpp compiled for the host: the persistent worker behind every handle's threads (FIFO
+    order, return codes and the worker thread's error text, exceptions caught inside the job, queued jobs run
+    at stop), the lock-pages page arithmetic on ADVICE r2's example, and the page-lock registry's paths that
+    need no device (a failed registration leaves no record; releasing an unknown block is refused)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_stage_test")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(root, "tests", "cpp", "host_stage_test.cpp"), "-o", exe,
+                           "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stdout + p.stderr
