@@ -233,7 +233,9 @@ def coder_path(frames=BATCH_PER_GPU, iters=40, snr=2.6, repeat=3, timeout=600):
             "what": "CoderBench 0 %d %d %d %.1f SP --iters %d: Test.cpp's sequence on Coder(32400, 64800, rate_1_2); decode() = "
                     "ldpc_decode with poll_interval 4 from malloc'ed buffers (default input mode: staged), PCIe included; "
                     "ThroughPut = info bytes per wall-clock second of the best of %d decode() calls (the reference prints "
-                    "CPU seconds, Test.cpp:111); encode() is the structured O(E) encoder, single-threaded on the host"
+                    "CPU seconds, Test.cpp:111); at 2.6 dB the reference's fixed exp(8 y) sum-product leaves frames unconverged (ErrNum > 0, "
+                    "Time = 40): the call does full work, as the headline step does; encode() is the structured O(E) encoder on "
+                    "z-bit words, single-threaded on the host"
                     % (N_CODE, frames, frames, snr, iters, repeat)}
 
 
