@@ -458,6 +458,7 @@ def main():
     st = dec.stats()
     kt = dec.kernel_times()
     link_form = dec.link_form()          # which form of the column-fused check kernel the creation-time timing picked
+    placement = dec.placement()          # ... and on which of the candidate sets of arrays it runs
     assert st["iterations_launched"] == ITERS
     launch_frames = B
     flood = [k for k in kt if k["phase"] in (0, 1)]
@@ -470,7 +471,7 @@ def main():
     except Exception:
         probe = probe_default = probe_nt = None
     mine = {"rank": rank, "device": local_rank, "ms_per_step": round(dt_own / args.steps * 1e3, 3),
-            "kernel": dom["name"], "kernel_form": None if not link_form else link_form["form"], "avg_launch_ms": round(dom["ms_total"] / dom["launches"], 4),
+            "kernel": dom["name"], "kernel_form": None if not link_form else link_form["form"], "placement": placement, "avg_launch_ms": round(dom["ms_total"] / dom["launches"], 4),
             "hbm_probe_gbs": None if probe is None else round(probe, 1)}
     per_rank = [mine]
     if world > 1:
@@ -537,7 +538,7 @@ def main():
                       # copy rate its GPU delivered right after the timed steps
                       "per_rank": per_rank},
             "roofline": {
-                "bound": "hbm", "kernel": dom["name"], "kernel_form": link_form, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": dom["name"], "kernel_form": link_form, "placement": placement, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_note,
                 "avg_launch_ms": round(dom_avg_ms, 4), "launches": dom["launches"],

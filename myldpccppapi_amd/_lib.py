@@ -33,7 +33,8 @@ class DecoderConfig(ctypes.Structure):
                 ("tune_flags", ctypes.c_int32), ("tune_rows_per_wave", ctypes.c_int32),
                 ("tune_cols_per_wave", ctypes.c_int32), ("tune_link_rows", ctypes.c_int32),
                 ("tune_compact", ctypes.c_int32), ("tune_ldsp_grid", ctypes.c_int32),
-                ("tune_ldsp_shape", ctypes.c_int32), ("host_input", ctypes.c_int32),
+                ("tune_ldsp_shape", ctypes.c_int32), ("tune_place", ctypes.c_int32),
+                ("host_input", ctypes.c_int32),
                 ("host_copy_threads", ctypes.c_int32)]
 
 
@@ -61,7 +62,7 @@ EXPORTS = (
     "ldpc_decoder_create_multi", "ldpc_shard_range", "ldpc_decoder_destroy", "ldpc_decode", "ldpc_decode_device", "ldpc_out_bytes",
     "ldpc_decoder_set_timing", "ldpc_decoder_stats", "ldpc_decoder_kernel_times", "ldpc_decoder_set_tap",
     "ldpc_decoder_dump", "ldpc_awgn_device", "ldpc_count_errors_device", "ldpc_hbm_probe_device", "ldpc_hbm_sustained_device",
-    "ldpc_host_block_plan", "ldpc_host_locked_ranges", "ldpc_decoder_link_form",
+    "ldpc_host_block_plan", "ldpc_host_locked_ranges", "ldpc_decoder_link_form", "ldpc_decoder_placement", "ldpc_decoder_array_addresses",
 )
 
 
@@ -117,6 +118,8 @@ def load():
     L.ldpc_host_block_plan.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                        ctypes.POINTER(ctypes.c_uint64)]
     L.ldpc_host_locked_ranges.argtypes = [i64p, i64p]
+    L.ldpc_decoder_array_addresses.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.ldpc_decoder_placement.argtypes = [vp, i32p, i32p, ctypes.POINTER(ctypes.c_float)]
     L.ldpc_decoder_link_form.argtypes = [vp, i32p, i32p, ctypes.POINTER(ctypes.c_float)]
     _lib = L
     return L

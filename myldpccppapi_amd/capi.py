@@ -22,7 +22,7 @@ ALGOS = {"sp": ALGO_SP, "ms": ALGO_MS, "layered": ALGO_LAYERED, "ms_fused": ALGO
 TUNE_FIELDS = {"fused": 0, "ldsp": 2, "ldsp_ext": 4, "ldsp_pack": 6, "link_narrow": 8, "check_wide": 10,
                "syn_xcd": 12, "fused_pack": 14, "fused_loop": 16, "device_tail": 18, "merge": 20, "link_deep": 22, "link_half": 24,
                "link_guided": 26, "tiles_first": 28}
-TUNE_INTS = ("rows_per_wave", "cols_per_wave", "link_rows", "compact", "ldsp_grid", "ldsp_per_cu", "ldsp_waves")
+TUNE_INTS = ("rows_per_wave", "cols_per_wave", "link_rows", "compact", "ldsp_grid", "ldsp_per_cu", "ldsp_waves", "place")
 
 
 def apply_tune(cfg, tune):
@@ -231,6 +231,22 @@ class Decoder:
             return None
         return {"form": ("wide", "narrow", "half")[form.value], "chosen_by_measurement": bool(cal.value),
                 "ms_per_launch": {"wide": round(ms[0], 4), "narrow": round(ms[1], 4), "half": round(ms[2], 4)}}
+
+    def placement(self):
+        """The creation-time placement search: per candidate set of arrays the column-fused check kernel's time per
+        launch, and which one was kept (None: no search was made)."""
+        n, kept = ctypes.c_int32(0), ctypes.c_int32(0)
+        ms = (ctypes.c_float * 8)()
+        _lib.check(_lib.load().ldpc_decoder_placement(self._h, ctypes.byref(n), ctypes.byref(kept), ms))
+        if n.value == 0:
+            return None
+        return {"candidates_ms": [round(ms[i], 4) for i in range(n.value)], "kept": kept.value}
+
+    def array_addresses(self):
+        """Device addresses of the streaming decoder's Q, R, channel and hard-bit arrays."""
+        a = (ctypes.c_uint64 * 4)()
+        _lib.check(_lib.load().ldpc_decoder_array_addresses(self._h, a))
+        return {"Q": int(a[0]), "R": int(a[1]), "chan": int(a[2]), "hard": int(a[3])}
 
     def set_tap(self, it):
         _lib.check(_lib.load().ldpc_decoder_set_tap(self._h, int(it)))

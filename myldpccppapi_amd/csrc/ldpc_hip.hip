@@ -210,6 +210,9 @@ struct ldpc_decoder {
     int tune_link_narrow = 1;           /* linked check kernel: 0 wide (V values per lane), 1 narrow (1), 2 half (2) */
     bool link_calibrated = false;       /* chosen by timing the candidates at creation */
     float link_cal_ms[3] = {0, 0, 0};   /* what the calibration measured per launch: [0] wide, [1] narrow, [2] half */
+    /* placement search (cfg.tune_place): the column-fused check kernel's time on each candidate set of arrays */
+    int place_candidates = 0, place_kept = 0;
+    float place_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int link_rpw = 16;                  /* rows per wave of the fused check kernel; 0 = fusion off */
     int tune_link_guided = 0;           /* tri-state: shorter row chunks at the end of the fused check launch */
     int tune_tiles_first = 0;           /* tri-state: flooding launches as (tiles, blocks) grids (flood_grid) */
@@ -334,6 +337,25 @@ struct ldpc_decoder {
 };
 
 namespace {
+
+/* a plain float4 copy (the measurement aid ldpc_hbm_probe_device; also the placement search's second opinion) */
+template <bool NT>
+__global__ __launch_bounds__(256) void hbm_probe_copy_kernel(const ldpc::vf4 *__restrict__ src, ldpc::vf4 *__restrict__ dst, size_t n4)
+{
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i = (size_t)blockIdx.x * 256 * 4 + threadIdx.x; i < n4; i += stride) {
+        ldpc::vf4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + (size_t)k * 256 < n4) v[k] = NT ? __builtin_nontemporal_load(&src[i + (size_t)k * 256]) : src[i + (size_t)k * 256];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + (size_t)k * 256 < n4) {
+                if (NT) __builtin_nontemporal_store(v[k], &dst[i + (size_t)k * 256]);
+                else dst[i + (size_t)k * 256] = v[k];
+            }
+    }
+}
 
 /* summary[0] = max over frames of iters (the reference's `Time=`), summary[1] =
  * number of frames whose syndrome ended clean. */
@@ -868,7 +890,8 @@ int setup_flooding(ldpc_decoder *d, const ldpc_graph *g, size_t TF)
  * own arrays when it is created -- interleaved launches, a few milliseconds -- and keeps the fastest
  * (wide also wins at 256 ... 1024 frames: +4 ... +8 % on the whole decode).  The arrays hold
  * zeros, which the first decode overwrites; results do not depend on the choice (the tests run both). */
-template <int V> int calibrate_link(ldpc_decoder *d)
+/* only_form >= 0: time that form alone (the placement search below) and report it in *form_ms; the decoder's choice stays */
+template <int V> int calibrate_link(ldpc_decoder *d, int only_form = -1, float *form_ms = nullptr)
 {
     using namespace ldpc;
     RowClass *rcp = nullptr;
@@ -888,6 +911,7 @@ template <int V> int calibrate_link(ldpc_decoder *d)
     hipError_t err = hipSuccess;
     for (int rep = 0; rep < 4 && err == hipSuccess; ++rep) {
         for (int nar = 0; nar < candidates && err == hipSuccess; ++nar) {
+            if (only_form >= 0 && nar != only_form) continue;
             CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, d->link_rpw, rc.degree, TailRef{nullptr, 0, 0}};
             LinkArgs lk{rc.link_col.p, rc.link_pos.p, d->chan.p, d->Q.p, d->hard.p, d->N, 1, 0, nullptr, nullptr, 0, 0,
                         rc.n_big, rc.small_rows};
@@ -907,11 +931,71 @@ template <int V> int calibrate_link(ldpc_decoder *d)
     (void)hipEventDestroy(ev[1]);
     if (err != hipSuccess) return fail(LDPC_ERR_HIP, "link calibration: %s", hipGetErrorString(err));
     HIP_TRY(hipGetLastError());
+    if (only_form >= 0) {
+        if (form_ms) *form_ms = best[only_form];
+        return LDPC_OK;
+    }
     int pick = 0;
     for (int k = 0; k < candidates; ++k) { d->link_cal_ms[k] = best[k]; if (best[k] < best[pick]) pick = k; }
     d->tune_link_narrow = pick;
     d->link_calibrated = true;
     return LDPC_OK;
+}
+
+/* Where the message arrays lie in device memory decides how fast the streaming check kernel runs: the same
+ * kernel on the same data takes 1.28, 1.32, 1.35 or 1.53 ms per launch depending on the allocation it works on,
+ * for as long as that allocation lives (tools/gpu_placement_probe2.py: six decoders alive in one process, each
+ * with its own time, round after round; virtual addresses, offsets inside an allocation, clocks, power and
+ * temperature do not predict it -- rounds 2 and 3 looked).  This was the "123 ms or 137 ms regime" of the step.  So
+ * a decoder whose arrays are large does not take its first allocation as it comes: it allocates up to
+ * `tune_place` (default 3) sets of Q / R / channel arrays, holding the earlier ones so that each gets memory of
+ * its own, times the chosen form of the column-fused check kernel on each, keeps the fastest and releases the
+ * rest.  Costs about 20 ms per candidate at creation and one extra set of arrays while it runs. */
+template <int V> int placement_search(ldpc_decoder *d, size_t TF)
+{
+    RowClass *rcp = nullptr;
+    for (auto &rc : d->row_classes) if (rc.linked) rcp = &rc;
+    if (!rcp) return LDPC_OK;
+    const size_t bq = TF * (size_t)d->E * d->msg_size, bc = TF * d->N * d->msg_size;
+    int want = d->tune.place == 0 ? (2 * bq + bc >= ((size_t)256 << 20) ? 3 : 1) : d->tune.place;
+    if (want <= 1) return LDPC_OK;
+    const int form = d->tune_link_narrow;
+    float ms0 = 0.0f;
+    int rc = calibrate_link<V>(d, form, &ms0);
+    if (rc) return rc;
+    struct Set { DevBuf<uint8_t> chan, Q, R; };
+    std::vector<Set> held;                       /* candidates that lost: kept alive until the search ends */
+    Set best;                                    /* empty: the decoder's own arrays are the best so far */
+    float best_ms = ms0;
+    d->place_ms[0] = ms0;
+    d->place_candidates = 1;
+    d->place_kept = 0;
+    for (int c = 1; c < want; ++c) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * (2 * bq + bc) + ((size_t)1 << 30)) break;
+        Set cand;
+        if (cand.chan.alloc(bc) != hipSuccess || cand.Q.alloc(bq) != hipSuccess || cand.R.alloc(bq) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        /* the candidate becomes the decoder's set for the measurement */
+        std::swap(d->chan, cand.chan); std::swap(d->Q, cand.Q); std::swap(d->R, cand.R);
+        float ms = 0.0f;
+        rc = calibrate_link<V>(d, form, &ms);
+        if (rc) return rc;
+        d->place_ms[c] = ms;
+        d->place_candidates = c + 1;
+        if (ms < best_ms) {                      /* the decoder keeps the new set; the old one waits for release */
+            best_ms = ms;
+            d->place_kept = c;
+            held.push_back(std::move(cand));
+        } else {                                 /* back to the previous set */
+            std::swap(d->chan, cand.chan); std::swap(d->Q, cand.Q); std::swap(d->R, cand.R);
+            held.push_back(std::move(cand));
+        }
+    }
+    if (d->link_calibrated) d->link_cal_ms[form] = best_ms;
+    return LDPC_OK;                              /* `held` releases the losers here */
 }
 
 }  // namespace
@@ -1191,6 +1275,10 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
             /* narrow or wide column-fused check kernel: measured here unless the caller says which */
             if (tune.link_narrow == 0 && tune.link_half == 0 && !tune.link_deep && d->V >= 2 && !t_creating_child) {
                 rc = d->V == 1 ? calibrate_link<1>(d) : d->V == 2 ? calibrate_link<2>(d) : calibrate_link<4>(d);
+                if (rc) return rc;
+            }
+            if (d->V >= 2 && !t_creating_child) {
+                rc = d->V == 2 ? placement_search<2>(d, TF) : placement_search<4>(d, TF);
                 if (rc) return rc;
             }
             if (d->tail_enabled) {
@@ -1857,6 +1945,25 @@ int ldpc_decoder_link_form(ldpc_decoder *d, int32_t *form, int32_t *calibrated, 
     return LDPC_OK;
 }
 
+int ldpc_decoder_placement(ldpc_decoder *d, int32_t *candidates, int32_t *kept, float ms[8])
+{
+    if (!d) return fail(LDPC_ERR_ARG, "decoder is NULL");
+    if (!d->shards.empty()) return ldpc_decoder_placement(d->shards[0], candidates, kept, ms);
+    if (candidates) *candidates = d->place_candidates;
+    if (kept) *kept = d->place_kept;
+    if (ms) for (int k = 0; k < 8; ++k) ms[k] = k < d->place_candidates ? d->place_ms[k] : 0.0f;
+    return LDPC_OK;
+}
+
+int ldpc_decoder_array_addresses(ldpc_decoder *d, uint64_t out[4])
+{
+    if (!d || !out) return fail(LDPC_ERR_ARG, "decoder/out is NULL");
+    if (!d->shards.empty()) return ldpc_decoder_array_addresses(d->shards[0], out);
+    out[0] = (uint64_t)(uintptr_t)d->Q.p; out[1] = (uint64_t)(uintptr_t)d->R.p;
+    out[2] = (uint64_t)(uintptr_t)d->chan.p; out[3] = (uint64_t)(uintptr_t)d->hard.p;
+    return LDPC_OK;
+}
+
 int ldpc_decoder_set_tap(ldpc_decoder *d, int32_t iter)
 {
     if (!d) return fail(LDPC_ERR_ARG, "decoder is NULL");
@@ -2001,27 +2108,6 @@ int ldpc_count_errors_device(const uint8_t *out_dev, const uint8_t *ref_dev, int
 /* ---- measurement aid: what this box's HBM sustains right now (a float4 copy: the figure the
  *      microarchitecture guide quotes as achievable, 6.3 of 8.0 TB/s), with the default cache policy
  *      and with the non-temporal one the streaming kernels use; the better of the two ------------ */
-extern "C++" {
-namespace {
-template <bool NT>
-__global__ __launch_bounds__(256) void hbm_probe_copy_kernel(const ldpc::vf4 *__restrict__ src, ldpc::vf4 *__restrict__ dst, size_t n4)
-{
-    const size_t stride = (size_t)gridDim.x * 256 * 4;
-    for (size_t i = (size_t)blockIdx.x * 256 * 4 + threadIdx.x; i < n4; i += stride) {
-        ldpc::vf4 v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (i + (size_t)k * 256 < n4) v[k] = NT ? __builtin_nontemporal_load(&src[i + (size_t)k * 256]) : src[i + (size_t)k * 256];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (i + (size_t)k * 256 < n4) {
-                if (NT) __builtin_nontemporal_store(v[k], &dst[i + (size_t)k * 256]);
-                else dst[i + (size_t)k * 256] = v[k];
-            }
-    }
-}
-}  // namespace
-}  // extern "C++"
 
 int ldpc_hbm_probe_device(int32_t device, int64_t bytes, int32_t reps, double *copy_gbs, double *by_policy)
 {
