@@ -128,8 +128,8 @@ typedef struct ldpc_decoder_config {
                                    (default and maximum 512); -1 = off                            */
     int32_t tune_ldsp_grid;     /* record kernels (ldsp_kernels.hpp): persistent workgroups        */
     int32_t tune_ldsp_shape;    /* workgroups per CU | waves per workgroup << 8                    */
-    int32_t tune_place;         /* streaming flooding decoders with a column-fused check kernel: how many sets of message
-                                   arrays are allocated and timed when the decoder is created; the fastest is kept, the
+    int32_t tune_place;         /* streaming flooding decoders: how many sets of message arrays are allocated and timed
+                                   (one check phase each) when the decoder is created; the fastest is kept, the
                                    others are released.  WHERE the arrays lie in device memory decides between speeds of
                                    the streaming check kernel that differ by up to 19 % and last as long as the allocation
                                    (DESIGN.md section 4).  0 = automatic (3 when the arrays hold at least 256 MiB and
@@ -279,7 +279,7 @@ int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t ca
 int ldpc_decoder_link_form(ldpc_decoder *d, int32_t *form, int32_t *calibrated, float ms[3]);
 
 /* The placement search of tune_place: how many array sets were timed (*candidates, 0 = no search), which was kept
- * (*kept) and the column-fused check kernel's time per launch on each (ms[0 .. *candidates), at most 8). */
+ * (*kept) and the time of one check phase on each (ms[0 .. *candidates), at most 8). */
 int ldpc_decoder_placement(ldpc_decoder *d, int32_t *candidates, int32_t *kept, float ms[8]);
 /* Measurement aid: device addresses of a streaming decoder's arrays, out[0..3] = Q, R, channel term, hard-bit masks. */
 int ldpc_decoder_array_addresses(ldpc_decoder *d, uint64_t out[4]);

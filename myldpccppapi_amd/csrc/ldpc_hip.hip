@@ -429,6 +429,64 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
                                   uint8_t *out_dev, int64_t out_bytes, int32_t *iters_dev,
                                   hipStream_t s, int start_round = 1);
 
+/* The check phase of round `it` (R_i = check(Q_{i-1})) over `tiles` tiles: the column-fused launch, the bucket
+ * launches and the classes launched alone.  Also what the placement search times. */
+template <int V> int enqueue_check_phase(ldpc_decoder *d, hipStream_t s, int tiles, int64_t frames, int it, int max_iter,
+                                         bool fat, const ldpc::TailRef &tr)
+{
+    using namespace ldpc;
+    constexpr int kIdleFat = 8;
+    const int64_t msz = d->msg_size;
+    for (auto &rc : d->row_classes) {
+        if (!rc.linked) continue;
+        /* algorithmic bytes: the fused columns' messages and channel values count as in the
+         * two-kernel formulation (16 E + 4 N per frame-iteration in total).
+         * moved: every Q of the class and the fused columns' channel values in; R of the unfused
+         * edges and the fused columns' new Q out.  Rows riding along: Q in, R out. */
+        HIP_TRY(span_begin(d, s, 4, rc.degree,
+                           (2 * msz * rc.degree * rc.count + msz * 5 * rc.linked + 2 * msz * d->extra_edges) * frames,
+                           msz * ((int64_t)rc.degree * rc.count + rc.linked +
+                                  ((int64_t)rc.degree * rc.count - 2 * rc.linked) +
+                                  (it < max_iter ? 2 * rc.linked : 0) + 2 * d->extra_edges) * frames));
+        CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree, tr};
+        LinkArgs lk{rc.link_col.p, rc.link_pos.p, d->chan.p, d->Q.p, d->hard.p, d->N,
+                    (it < max_iter) ? 1 : 0, d->tap_iter ? 1 : 0, d->extra_e0.p, d->extra_deg.p, d->n_extra, 0,
+                    rc.n_big, rc.small_rows};
+        a.rows_per_wave = d->link_rpw;
+        const int variant = (d->tune_link_narrow == 2 && !d->link_half_fn[rc.degree]) ? 1 : d->tune_link_narrow;
+        const int waves = link_chunk_count(d->link_rpw, rc.n_big, rc.small_rows, rc.count) * (variant == 1 ? V : variant == 2 ? V / 2 : 1);
+        lk.link_blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+        /* tiles vary fastest: the short chunks of all tiles are the launch's last blocks */
+        const dim3 grid = flood_grid(d, lk.link_blocks + (d->n_extra + kWavesPerBlock - 1) / kWavesPerBlock, tiles, &a.tiles_first, true);
+        (variant == 2 ? d->link_half_fn : variant == 1 ? (d->tune_link_deep ? d->link_deep_fn : d->link_narrow_fn) : d->link_fn)
+            [rc.degree]<<<grid, kBlock, 0, s>>>(a, lk);
+        HIP_TRY(span_end(d, s));
+    }
+    for (auto &g : d->check_groups) {
+        int64_t edges = 0;
+        for (int i : g.members) edges += (int64_t)d->row_classes[i].degree * d->row_classes[i].count;
+        HIP_TRY(span_begin(d, s, 5, g.hi, 2 * msz * edges * frames, -1, g.lo));
+        CheckArgs a{d->Q.p, d->R.p, nullptr, d->done.p, d->E, 0, (d->tune_rpw ? d->tune_rpw : 2) * (fat ? kIdleFat : 1), 0, tr};
+        const dim3 grid = flood_grid(d, fat ? g.blocks_fat : g.blocks, tiles, &a.tiles_first);
+        d->check_group_fn[g.bucket]<<<grid, kBlock, 0, s>>>(a, fat ? g.table_fat.p : g.table.p, (int)g.members.size());
+        HIP_TRY(span_end(d, s));
+    }
+    for (int ci : d->check_solo) {
+        RowClass &rc = d->row_classes[ci];
+        HIP_TRY(span_begin(d, s, 0, rc.degree, 2 * msz * rc.degree * rc.count * frames));
+        CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree, tr};
+        const int slotk = rc.degree <= d->max_check_unrolled ? rc.degree : 0;
+        const bool narrow = slotk && (!d->tune_check_wide || rc.degree > kMaxUnrolledDegree);
+        const int rpw = (d->tune_rpw ? d->tune_rpw : (narrow ? 2 : 1)) * (fat ? kIdleFat : 1);
+        a.rows_per_wave = rpw;
+        const int waves = ((rc.count + rpw - 1) / rpw) * (narrow ? V : 1);
+        const dim3 grid = flood_grid(d, (waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles, &a.tiles_first);
+        (narrow ? d->check_fn : d->check_fn_wide)[slotk]<<<grid, kBlock, 0, s>>>(a);
+        HIP_TRY(span_end(d, s));
+    }
+    return LDPC_OK;
+}
+
 /* Hand the `count` frames that are still running after round `it` over to the child decoder, let it
  * finish them (rounds it+1 ...), and bring their bits, iteration counts and converged flags back. */
 template <int V> int compact_and_finish(ldpc_decoder *d, int64_t frames, int count, int it, hipStream_t s)
@@ -541,52 +599,9 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
     for (int it = start_round; it <= rounds; ++it) {
         const bool fat = idle_after > 0 && it > idle_after;      /* probably idle: fewer, fatter workgroups */
         /* check_i: R_i = check(Q_{i-1}) */
-        for (auto &rc : d->row_classes) {
-            if (!rc.linked) continue;
-            /* algorithmic bytes: the fused columns' messages and channel values count as in the
-             * two-kernel formulation (16 E + 4 N per frame-iteration in total).
-             * moved: every Q of the class and the fused columns' channel values in; R of the unfused
-             * edges and the fused columns' new Q out.  Rows riding along: Q in, R out. */
-            HIP_TRY(span_begin(d, s, 4, rc.degree,
-                               (2 * msz * rc.degree * rc.count + msz * 5 * rc.linked + 2 * msz * d->extra_edges) * frames,
-                               msz * ((int64_t)rc.degree * rc.count + rc.linked +
-                                      ((int64_t)rc.degree * rc.count - 2 * rc.linked) +
-                                      (it < max_iter ? 2 * rc.linked : 0) + 2 * d->extra_edges) * frames));
-            CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree, tr};
-            LinkArgs lk{rc.link_col.p, rc.link_pos.p, d->chan.p, d->Q.p, d->hard.p, d->N,
-                        (it < max_iter) ? 1 : 0, d->tap_iter ? 1 : 0, d->extra_e0.p, d->extra_deg.p, d->n_extra, 0,
-                        rc.n_big, rc.small_rows};
-            a.rows_per_wave = d->link_rpw;
-            const int variant = (d->tune_link_narrow == 2 && !d->link_half_fn[rc.degree]) ? 1 : d->tune_link_narrow;
-            const int waves = link_chunk_count(d->link_rpw, rc.n_big, rc.small_rows, rc.count) * (variant == 1 ? V : variant == 2 ? V / 2 : 1);
-            lk.link_blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
-            /* tiles vary fastest: the short chunks of all tiles are the launch's last blocks */
-            const dim3 grid = flood_grid(d, lk.link_blocks + (d->n_extra + kWavesPerBlock - 1) / kWavesPerBlock, tiles, &a.tiles_first, true);
-            (variant == 2 ? d->link_half_fn : variant == 1 ? (d->tune_link_deep ? d->link_deep_fn : d->link_narrow_fn) : d->link_fn)
-                [rc.degree]<<<grid, kBlock, 0, s>>>(a, lk);
-            HIP_TRY(span_end(d, s));
-        }
-        for (auto &g : d->check_groups) {
-            int64_t edges = 0;
-            for (int i : g.members) edges += (int64_t)d->row_classes[i].degree * d->row_classes[i].count;
-            HIP_TRY(span_begin(d, s, 5, g.hi, 2 * msz * edges * frames, -1, g.lo));
-            CheckArgs a{d->Q.p, d->R.p, nullptr, d->done.p, d->E, 0, (d->tune_rpw ? d->tune_rpw : 2) * (fat ? kIdleFat : 1), 0, tr};
-            const dim3 grid = flood_grid(d, fat ? g.blocks_fat : g.blocks, tiles, &a.tiles_first);
-            d->check_group_fn[g.bucket]<<<grid, kBlock, 0, s>>>(a, fat ? g.table_fat.p : g.table.p, (int)g.members.size());
-            HIP_TRY(span_end(d, s));
-        }
-        for (int ci : d->check_solo) {
-            RowClass &rc = d->row_classes[ci];
-            HIP_TRY(span_begin(d, s, 0, rc.degree, 2 * msz * rc.degree * rc.count * frames));
-            CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree, tr};
-            const int slotk = rc.degree <= d->max_check_unrolled ? rc.degree : 0;
-            const bool narrow = slotk && (!d->tune_check_wide || rc.degree > kMaxUnrolledDegree);
-            const int rpw = (d->tune_rpw ? d->tune_rpw : (narrow ? 2 : 1)) * (fat ? kIdleFat : 1);
-            a.rows_per_wave = rpw;
-            const int waves = ((rc.count + rpw - 1) / rpw) * (narrow ? V : 1);
-            const dim3 grid = flood_grid(d, (waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles, &a.tiles_first);
-            (narrow ? d->check_fn : d->check_fn_wide)[slotk]<<<grid, kBlock, 0, s>>>(a);
-            HIP_TRY(span_end(d, s));
+        {
+            const int rcp = enqueue_check_phase<V>(d, s, tiles, frames, it, max_iter, fat, tr);
+            if (rcp) return rcp;
         }
         /* var_i: bits_i = hard(R_i); Q_i = var(R_i) unless this is the last round */
         const int wq = (it < max_iter) ? 1 : 0;
@@ -890,8 +905,7 @@ int setup_flooding(ldpc_decoder *d, const ldpc_graph *g, size_t TF)
  * own arrays when it is created -- interleaved launches, a few milliseconds -- and keeps the fastest
  * (wide also wins at 256 ... 1024 frames: +4 ... +8 % on the whole decode).  The arrays hold
  * zeros, which the first decode overwrites; results do not depend on the choice (the tests run both). */
-/* only_form >= 0: time that form alone (the placement search below) and report it in *form_ms; the decoder's choice stays */
-template <int V> int calibrate_link(ldpc_decoder *d, int only_form = -1, float *form_ms = nullptr)
+template <int V> int calibrate_link(ldpc_decoder *d)
 {
     using namespace ldpc;
     RowClass *rcp = nullptr;
@@ -911,7 +925,6 @@ template <int V> int calibrate_link(ldpc_decoder *d, int only_form = -1, float *
     hipError_t err = hipSuccess;
     for (int rep = 0; rep < 4 && err == hipSuccess; ++rep) {
         for (int nar = 0; nar < candidates && err == hipSuccess; ++nar) {
-            if (only_form >= 0 && nar != only_form) continue;
             CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, d->link_rpw, rc.degree, TailRef{nullptr, 0, 0}};
             LinkArgs lk{rc.link_col.p, rc.link_pos.p, d->chan.p, d->Q.p, d->hard.p, d->N, 1, 0, nullptr, nullptr, 0, 0,
                         rc.n_big, rc.small_rows};
@@ -931,10 +944,6 @@ template <int V> int calibrate_link(ldpc_decoder *d, int only_form = -1, float *
     (void)hipEventDestroy(ev[1]);
     if (err != hipSuccess) return fail(LDPC_ERR_HIP, "link calibration: %s", hipGetErrorString(err));
     HIP_TRY(hipGetLastError());
-    if (only_form >= 0) {
-        if (form_ms) *form_ms = best[only_form];
-        return LDPC_OK;
-    }
     int pick = 0;
     for (int k = 0; k < candidates; ++k) { d->link_cal_ms[k] = best[k]; if (best[k] < best[pick]) pick = k; }
     d->tune_link_narrow = pick;
@@ -942,30 +951,55 @@ template <int V> int calibrate_link(ldpc_decoder *d, int only_form = -1, float *
     return LDPC_OK;
 }
 
-/* Where the message arrays lie in device memory decides how fast the streaming check kernel runs: the same
- * kernel on the same data takes 1.28, 1.32, 1.35 or 1.53 ms per launch depending on the allocation it works on,
+/* One whole check phase over all tiles of the decoder on zeroed arrays, best of three timed launches (ms). */
+template <int V> int time_check_phase(ldpc_decoder *d, float *ms_out)
+{
+    hipStream_t s = d->stream;
+    HIP_TRY(hipMemsetAsync(d->Q.p, 0, d->Q.n, s));
+    HIP_TRY(hipMemsetAsync(d->chan.p, 0, d->chan.n, s));
+    HIP_TRY(hipMemsetAsync(d->done.p, 0, d->done.n * sizeof(uint64_t), s));
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    HIP_TRY(hipEventCreate(&ev[0]));
+    HIP_TRY(hipEventCreate(&ev[1]));
+    float best = 1e30f;
+    hipError_t err = hipSuccess;
+    int rc = LDPC_OK;
+    for (int rep = 0; rep < 4 && err == hipSuccess && rc == LDPC_OK; ++rep) {
+        err = hipEventRecord(ev[0], s);
+        rc = enqueue_check_phase<V>(d, s, d->T, (int64_t)d->T * d->F, 1, d->cfg.max_iter, false, ldpc::TailRef{nullptr, 0, 0});
+        if (err == hipSuccess) err = hipEventRecord(ev[1], s);
+        if (err == hipSuccess) err = hipEventSynchronize(ev[1]);
+        float ms = 0;
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, ev[0], ev[1]);
+        if (err == hipSuccess && rep > 0 && ms < best) best = ms;          /* rep 0 warms up */
+    }
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    if (rc) return rc;
+    if (err != hipSuccess) return fail(LDPC_ERR_HIP, "placement search: %s", hipGetErrorString(err));
+    *ms_out = best;
+    return LDPC_OK;
+}
+
+/* Where the message arrays lie in device memory decides how fast the streaming check kernels run: the same
+ * kernel on the same data takes 1.27, 1.30, 1.35 or 1.53 ms per launch depending on the allocation it works on,
  * for as long as that allocation lives (tools/gpu_placement_probe2.py: six decoders alive in one process, each
  * with its own time, round after round; virtual addresses, offsets inside an allocation, clocks, power and
- * temperature do not predict it -- rounds 2 and 3 looked).  This was the "123 ms or 137 ms regime" of the step.  So
- * a decoder whose arrays are large does not take its first allocation as it comes: it allocates up to
- * `tune_place` (default 3) sets of Q / R / channel arrays, holding the earlier ones so that each gets memory of
- * its own, times the chosen form of the column-fused check kernel on each, keeps the fastest and releases the
- * rest.  Costs about 20 ms per candidate at creation and one extra set of arrays while it runs. */
+ * temperature do not predict it -- rounds 2 and 3 looked; profiles/r03_placement_search.txt).  This was the
+ * "123 ms or 137 ms regime" of the headline step.  So a decoder whose arrays are large does not take its first
+ * allocation as it comes: it allocates up to `tune_place` (default 3) sets of Q / R / channel arrays, holding the
+ * earlier ones so that each gets memory of its own, times its check phase on each, keeps the fastest and
+ * releases the rest.  About 20 ms per candidate at creation and two extra sets of arrays while it runs. */
 template <int V> int placement_search(ldpc_decoder *d, size_t TF)
 {
-    RowClass *rcp = nullptr;
-    for (auto &rc : d->row_classes) if (rc.linked) rcp = &rc;
-    if (!rcp) return LDPC_OK;
     const size_t bq = TF * (size_t)d->E * d->msg_size, bc = TF * d->N * d->msg_size;
-    int want = d->tune.place == 0 ? (2 * bq + bc >= ((size_t)256 << 20) ? 3 : 1) : d->tune.place;
+    const int want = d->tune.place == 0 ? (2 * bq + bc >= ((size_t)256 << 20) ? 3 : 1) : d->tune.place;
     if (want <= 1) return LDPC_OK;
-    const int form = d->tune_link_narrow;
     float ms0 = 0.0f;
-    int rc = calibrate_link<V>(d, form, &ms0);
+    int rc = time_check_phase<V>(d, &ms0);
     if (rc) return rc;
     struct Set { DevBuf<uint8_t> chan, Q, R; };
-    std::vector<Set> held;                       /* candidates that lost: kept alive until the search ends */
-    Set best;                                    /* empty: the decoder's own arrays are the best so far */
+    std::vector<Set> held;                       /* the sets that lost: kept alive until the search ends */
     float best_ms = ms0;
     d->place_ms[0] = ms0;
     d->place_candidates = 1;
@@ -981,20 +1015,18 @@ template <int V> int placement_search(ldpc_decoder *d, size_t TF)
         /* the candidate becomes the decoder's set for the measurement */
         std::swap(d->chan, cand.chan); std::swap(d->Q, cand.Q); std::swap(d->R, cand.R);
         float ms = 0.0f;
-        rc = calibrate_link<V>(d, form, &ms);
+        rc = time_check_phase<V>(d, &ms);
         if (rc) return rc;
         d->place_ms[c] = ms;
         d->place_candidates = c + 1;
         if (ms < best_ms) {                      /* the decoder keeps the new set; the old one waits for release */
             best_ms = ms;
             d->place_kept = c;
-            held.push_back(std::move(cand));
         } else {                                 /* back to the previous set */
             std::swap(d->chan, cand.chan); std::swap(d->Q, cand.Q); std::swap(d->R, cand.R);
-            held.push_back(std::move(cand));
         }
+        held.push_back(std::move(cand));
     }
-    if (d->link_calibrated) d->link_cal_ms[form] = best_ms;
     return LDPC_OK;                              /* `held` releases the losers here */
 }
 
@@ -1277,8 +1309,8 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
                 rc = d->V == 1 ? calibrate_link<1>(d) : d->V == 2 ? calibrate_link<2>(d) : calibrate_link<4>(d);
                 if (rc) return rc;
             }
-            if (d->V >= 2 && !t_creating_child) {
-                rc = d->V == 2 ? placement_search<2>(d, TF) : placement_search<4>(d, TF);
+            if (!t_creating_child) {
+                rc = d->V == 1 ? placement_search<1>(d, TF) : d->V == 2 ? placement_search<2>(d, TF) : placement_search<4>(d, TF);
                 if (rc) return rc;
             }
             if (d->tail_enabled) {
