@@ -128,12 +128,14 @@ typedef struct ldpc_decoder_config {
                                    (default and maximum 512); -1 = off                            */
     int32_t tune_ldsp_grid;     /* record kernels (ldsp_kernels.hpp): persistent workgroups        */
     int32_t tune_ldsp_shape;    /* workgroups per CU | waves per workgroup << 8                    */
-    int32_t tune_place;         /* streaming flooding decoders: how many sets of message arrays are allocated and timed
-                                   (one check phase each) when the decoder is created; the fastest is kept, the
-                                   others are released.  WHERE the arrays lie in device memory decides between speeds of
-                                   the streaming check kernel that differ by up to 19 % and last as long as the allocation
-                                   (DESIGN.md section 4).  0 = automatic (3 when the arrays hold at least 256 MiB and
-                                   memory allows), 1 = take the first allocation as it comes, 2..8 = that many  */
+    int32_t tune_place;         /* streaming flooding decoders: fresh allocations tried for the check->variable and for
+                                   the variable->check array when the decoder is created (one check phase is timed with
+                                   each; the fastest combination is kept, the others are released).  WHICH allocations
+                                   lie behind these two arrays decides between speeds of the streaming check kernel that
+                                   differ by up to 19 % and last as long as the allocations.
+                                   0 = automatic (up to 5 per array when the arrays hold at least 256 MiB and memory
+                                   allows; a stage stops once it has seen both speeds), 1 = take the first allocations
+                                   as they come, 2..8 = that many per array                              */
     int32_t host_input;         /* enum ldpc_host_input: how ldpc_decode() moves the caller's pageable channel
                                    values to the device (memory the caller has page-locked itself is always
                                    copied from directly)                                               */
@@ -278,8 +280,9 @@ int ldpc_decoder_kernel_times(ldpc_decoder *d, ldpc_kernel_time *out, int32_t ca
  * the form was fixed by the tuning fields or the code has no column-fused rows). */
 int ldpc_decoder_link_form(ldpc_decoder *d, int32_t *form, int32_t *calibrated, float ms[3]);
 
-/* The placement search of tune_place: how many array sets were timed (*candidates, 0 = no search), which was kept
- * (*kept) and the time of one check phase on each (ms[0 .. *candidates), at most 8). */
+/* The placement search of tune_place: how many combinations were timed (*candidates, 0 = no search; the first is the
+ * decoder's original allocations, then fresh R arrays, then fresh Q arrays), which was kept (*kept) and the time of one
+ * check phase with each (ms[0 .. *candidates), at most 8 are reported). */
 int ldpc_decoder_placement(ldpc_decoder *d, int32_t *candidates, int32_t *kept, float ms[8]);
 /* Measurement aid: device addresses of a streaming decoder's arrays, out[0..3] = Q, R, channel term, hard-bit masks. */
 int ldpc_decoder_array_addresses(ldpc_decoder *d, uint64_t out[4]);

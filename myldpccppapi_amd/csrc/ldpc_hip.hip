@@ -982,52 +982,56 @@ template <int V> int time_check_phase(ldpc_decoder *d, float *ms_out)
 }
 
 /* Where the message arrays lie in device memory decides how fast the streaming check kernels run: the same
- * kernel on the same data takes 1.27, 1.30, 1.35 or 1.53 ms per launch depending on the allocation it works on,
- * for as long as that allocation lives (tools/gpu_placement_probe2.py: six decoders alive in one process, each
- * with its own time, round after round; virtual addresses, offsets inside an allocation, clocks, power and
- * temperature do not predict it -- rounds 2 and 3 looked; profiles/r03_placement_search.txt).  This was the
- * "123 ms or 137 ms regime" of the headline step.  So a decoder whose arrays are large does not take its first
- * allocation as it comes: it allocates up to `tune_place` (default 3) sets of Q / R / channel arrays, holding the
- * earlier ones so that each gets memory of its own, times its check phase on each, keeps the fastest and
- * releases the rest.  About 20 ms per candidate at creation and two extra sets of arrays while it runs. */
+ * kernel on the same data takes 1.27, 1.35 or 1.53 ms per launch depending on the allocations it works on, for
+ * as long as they live (tools/gpu_placement_probe2.py: six decoders alive in one process, each with its own time,
+ * round after round; virtual addresses, offsets inside an allocation, clocks, power and temperature do not predict
+ * it -- rounds 2 and 3 looked; profiles/r03_placement_search.txt).  This was the "123 ms or 137 ms regime" of the
+ * headline step.  It is a property of the PAIR of allocations behind Q and R: with Q fixed some fresh R allocations
+ * are fast and some slow, with R fixed the same holds for Q, the channel array does not matter
+ * (tools/gpu_array_trials.py), and consecutive allocations tend to share their luck.  So a decoder whose arrays are
+ * large does not take its first allocations as they come: holding what it has, it tries up to `tune_place`
+ * (default 5) fresh allocations for R, then for Q, times one whole check phase with each, keeps the fastest and
+ * releases the rest at the end; a stage stops as soon as it has seen both speeds (a candidate at least 6 % faster
+ * than another).  About 10 ms and 4 GB per candidate while the decoder is being created. */
 template <int V> int placement_search(ldpc_decoder *d, size_t TF)
 {
     const size_t bq = TF * (size_t)d->E * d->msg_size, bc = TF * d->N * d->msg_size;
-    const int want = d->tune.place == 0 ? (2 * bq + bc >= ((size_t)256 << 20) ? 3 : 1) : d->tune.place;
+    const int want = d->tune.place == 0 ? (2 * bq + bc >= ((size_t)256 << 20) ? 5 : 1) : d->tune.place;
     if (want <= 1) return LDPC_OK;
-    float ms0 = 0.0f;
-    int rc = time_check_phase<V>(d, &ms0);
+    float best_ms = 0.0f;
+    int rc = time_check_phase<V>(d, &best_ms);
     if (rc) return rc;
-    struct Set { DevBuf<uint8_t> chan, Q, R; };
-    std::vector<Set> held;                       /* the sets that lost: kept alive until the search ends */
-    float best_ms = ms0;
-    d->place_ms[0] = ms0;
+    std::vector<DevBuf<uint8_t>> held;           /* the allocations that lost: kept alive until the search ends */
+    d->place_ms[0] = best_ms;
     d->place_candidates = 1;
     d->place_kept = 0;
-    for (int c = 1; c < want; ++c) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * (2 * bq + bc) + ((size_t)1 << 30)) break;
-        Set cand;
-        if (cand.chan.alloc(bc) != hipSuccess || cand.Q.alloc(bq) != hipSuccess || cand.R.alloc(bq) != hipSuccess) {
-            (void)hipGetLastError();
-            break;
+    float lo = best_ms, hi = best_ms;
+    for (int stage = 0; stage < 2; ++stage) {
+        DevBuf<uint8_t> &arr = stage == 0 ? d->R : d->Q;
+        for (int c = 1; c < want; ++c) {
+            if (lo < 0.94f * hi && best_ms <= lo) break;                 /* both speeds seen, the fast one is kept */
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * bq + ((size_t)2 << 30)) break;
+            DevBuf<uint8_t> cand;
+            if (cand.alloc(arr.n) != hipSuccess) { (void)hipGetLastError(); break; }
+            std::swap(arr, cand);                                        /* the candidate is the decoder's array now */
+            float ms = 0.0f;
+            rc = time_check_phase<V>(d, &ms);
+            if (rc) return rc;
+            if (d->place_candidates < 8) d->place_ms[d->place_candidates] = ms;
+            lo = std::min(lo, ms); hi = std::max(hi, ms);
+            if (ms < best_ms) {
+                best_ms = ms;
+                d->place_kept = d->place_candidates;
+            } else {
+                std::swap(arr, cand);                                    /* back to the array it had */
+            }
+            ++d->place_candidates;
+            held.push_back(std::move(cand));
         }
-        /* the candidate becomes the decoder's set for the measurement */
-        std::swap(d->chan, cand.chan); std::swap(d->Q, cand.Q); std::swap(d->R, cand.R);
-        float ms = 0.0f;
-        rc = time_check_phase<V>(d, &ms);
-        if (rc) return rc;
-        d->place_ms[c] = ms;
-        d->place_candidates = c + 1;
-        if (ms < best_ms) {                      /* the decoder keeps the new set; the old one waits for release */
-            best_ms = ms;
-            d->place_kept = c;
-        } else {                                 /* back to the previous set */
-            std::swap(d->chan, cand.chan); std::swap(d->Q, cand.Q); std::swap(d->R, cand.R);
-        }
-        held.push_back(std::move(cand));
     }
-    return LDPC_OK;                              /* `held` releases the losers here */
+    if (d->place_candidates > 8) d->place_candidates = 8;               /* what place_ms[] can report */
+    return LDPC_OK;                                                      /* `held` releases the losers here */
 }
 
 }  // namespace
