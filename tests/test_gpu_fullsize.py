@@ -399,3 +399,29 @@ def test_hbm_probe_reports_both_cache_policies(built):
     # the same copy back to back for 50 ms: a plausible rate too, not above the burst figure by more than noise
     sustained = L.capi.hbm_sustained(0, 256 << 20, 50)
     assert 1000.0 < sustained < 1.15 * best, (sustained, best)
+
+
+def test_placement_search_keeps_results_and_reports_what_it_saw(built, code):
+    """cfg.tune_place: a decoder with large arrays tries fresh allocations for its two message arrays when it is created
+    and keeps the fastest combination.  Results must not depend on it; the report must be sane; and
+    `place = 1` must skip the search."""
+    rows, cols, g, og = code
+    y = channel.awgn_frames(N, 0, 300, 0.9, seed=77)
+    ref = None
+    for place in (1, 0, 3):
+        dec = L.Decoder(g, K, max_batch=1024, algo="ms", max_iter=12, tune={"place": place})
+        rep = dec.placement()
+        if place == 1:
+            assert rep is None
+        else:
+            assert rep is not None and 1 <= len(rep["candidates_ms"]) <= 8 and 0 <= rep["kept"] < len(rep["candidates_ms"])
+            assert all(0.01 < t < 50 for t in rep["candidates_ms"])
+            assert rep["candidates_ms"][rep["kept"]] == min(rep["candidates_ms"])
+        out, iters = dec.decode(y)
+        if ref is None:
+            ref = (out, iters)
+            o = oracle.decode(og, y[:2], "ms", max_iter=12)
+            assert np.array_equal(out[:2 * K // 8], o["out"]) and np.array_equal(iters[:2], o["iters"])
+        assert np.array_equal(out, ref[0]) and np.array_equal(iters, ref[1]), place
+        assert set(dec.array_addresses()) == {"Q", "R", "chan", "hard"}
+        dec.close()
