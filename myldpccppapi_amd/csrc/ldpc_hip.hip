@@ -662,7 +662,10 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
                 HIP_TRY(hipStreamSynchronize(s));
                 const int running = *d->h_active;
                 if (running == 0) break;        /* every frame frozen: MyLdpc.cpp:1035-1036 */
-                if ((int64_t)running * 10 <= frames * 9 && d->child && tiles > 1) poll_dense = true;
+                /* ... where a round is long enough for a host round trip (about 25 us) not to matter: from 1.5 GB of
+                 * message traffic per round (about 0.3 ms) */
+                if ((int64_t)running * 10 <= frames * 9 && d->child && tiles > 1 &&
+                    (double)d->E * (double)frames * 4.0 * (double)msz > 1.5e9) poll_dense = true;
                 if (d->child && running <= d->compact_threshold && (int64_t)running * 4 <= frames && tiles > 1 && !d->tap_iter) {
                     const int rc = compact_and_finish<V>(d, frames, running, it, s);
                     if (rc) return rc;

@@ -278,3 +278,30 @@ def test_two_handles_decode_the_same_buffer_concurrently(built):
                 assert np.array_equal(out, want[0]) and np.array_equal(iters, want[1]), mode
             decs[i].close()
         assert L.capi.host_locked_ranges() == (0, 0)
+
+
+@pytest.mark.parametrize("threads", [1, 2, 16])
+def test_staged_input_with_any_number_of_copy_threads(built, threads):
+    """host_copy_threads = 1 (the stager alone, no helpers), 2 and 16 (the maximum): groups just above and just below the
+    4 MiB small-group limit, a call without iteration counts, and an output buffer shorter than the decoded stream
+    (Coder::decode writes srcLength bytes, MyLdpc.cpp:571-618)."""
+    import ctypes
+    g, og, K, M, z = _graph(codes.RATE_1_2, 2304)
+    y = channel.awgn_frames(2304, 0, 1000, 0.8, seed=64)
+    want = oracle.decode(og, y[:96], "ms", max_iter=20)
+    ref = None
+    for B in (455, 456, 1000):                       # 455 * 2304 * 4 = 4 193 280 B < 4 MiB < 456 * 2304 * 4
+        dec = L.Decoder(g, K, max_batch=B, algo="ms", max_iter=20, tune={"fused": False, "ldsp": False},
+                        host_copy_threads=threads)
+        out, iters = dec.decode(y)
+        if ref is None:
+            ref = (out, iters)
+            assert np.array_equal(out[:96 * K // 8], want["out"]) and np.array_equal(iters[:96], want["iters"])
+        assert np.array_equal(out, ref[0]) and np.array_equal(iters, ref[1]), B
+        out2, _ = dec.decode(y, want_iters=False)
+        assert np.array_equal(out2, ref[0])
+        short = np.full(1000, 0xEE, np.uint8)        # room for 6 frames and 136 bytes of the 7th; the rest stays untouched
+        from myldpccppapi_amd import _lib
+        _lib.check(_lib.load().ldpc_decode(dec._h, y.ctypes.data, 1000, short.ctypes.data, 1000, None))
+        assert np.array_equal(short, ref[0][:1000])
+        dec.close()
