@@ -111,6 +111,7 @@ def measure_extra(name, steps, warmup, batch=0, sigma=0.0, fpl=0, poll=-1, tune=
                       "avg_iterations_per_frame": round(frame_iters / B, 2),
                       "frames_converged": st["frames_converged"],
                       "bit_errors_in_converged_frames": int(np.unpackbits(out.cpu().numpy().reshape(B, -1)[iters < c["iters"]]).sum())}}
+    res["config"]["placement"] = dec.placement()      # streaming decoders with large arrays: what the creation-time search saw
     if one_launch:
         # LDS / cache resident decode (one launch; frame state in LDS, check records in L2 / Infinity Cache): HBM sees
         # the channel values in and the packed bits out only, so HBM is not what bounds it.  The kernel is bound by
