@@ -15,7 +15,7 @@ g = L.Graph(rows, cols, N - K, N)
 y = channel.awgn_device(N, 0, B, 0.95, seed=20260101)
 out = torch.empty(L.out_bytes(K, B), dtype=torch.uint8, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
-decs = [L.Decoder(g, K, max_batch=B, algo="sp", max_iter=50, tune={"link_narrow": False, "link_half": False}) for _ in range(n)]
+decs = [L.Decoder(g, K, max_batch=B, algo="sp", max_iter=50, tune={"link_narrow": False, "link_half": False, "place": 1}) for _ in range(n)]
 for r in range(rounds):
     for i, dec in enumerate(decs):
         dec.set_timing(True)
