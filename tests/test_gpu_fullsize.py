@@ -327,6 +327,46 @@ def test_rate_910_fp16_early_termination_at_its_full_batch_of_4096(built):
         assert iters[f] == o["iters"][0], f
 
 
+def test_hand_over_of_hundreds_of_frames_is_bit_exact(built, code):
+    """Round 3's large hand-over: once a poll has seen a tenth of the frames finished the host polls every round, and up to
+    1024 running frames (a quarter of a 4096-frame batch) move to the child through the row-wise LDS gather and the
+    atomics-free way back (compact_gather_rows_kernel, compact_hard_back_kernel).  (a) configs[4]'s own operating point --
+    rate 9/10, fp16, sigma 0.43: 681 frames still run after round 5 -- and (b) the headline code, fp32 min-sum, 4096 frames
+    of which 700 are noisier.  Bytes and iteration counts of ALL frames equal an unpolled, uncompacted run; fewer
+    tile-rounds do work; samples equal the oracle."""
+    rows, cols, g, og = code
+    cases = []
+    N2, K2 = 64800, 58320
+    r2, c2 = codes.dvbs2_profile_edges(N2, K2)
+    cases.append(("f16", L.Graph(r2, c2, N2 - K2, N2), oracle.Graph(r2, c2, N2 - K2, N2, K2), N2, K2,
+                  channel.awgn_device(N2, 0, 4096, 0.43, seed=20260101).cpu().numpy(), 50, [0, 2047, 4095]))
+    rng = np.random.default_rng(91)
+    y = (1.0 + 0.70 * rng.standard_normal((4096, N), dtype=np.float32)).astype(np.float32)
+    slow = np.sort(rng.choice(4096, 700, replace=False))
+    y[slow] = (1.0 + 0.80 * rng.standard_normal((700, N), dtype=np.float32)).astype(np.float32)
+    cases.append(("f32", g, og, N, K, y, 30, [int(slow[0]), int(slow[350]), 1]))
+    for msg, gg, ogg, n_, k_, yy, max_iter, pick in cases:
+        ref = L.Decoder(gg, k_, max_batch=4096, algo="ms", max_iter=max_iter, msg_dtype=msg, poll_interval=0,
+                        tune={"compact": -1, "device_tail": False})
+        out_ref, it_ref = ref.decode(yy)
+        fr_ref = ref.stats()["frame_rounds"]
+        ref.close()
+        dec = L.Decoder(gg, k_, max_batch=4096, algo="ms", max_iter=max_iter, msg_dtype=msg, poll_interval=2)
+        out, iters = dec.decode(yy)
+        st = dec.stats()
+        dec.close()
+        assert np.array_equal(iters, it_ref) and np.array_equal(out, out_ref), msg
+        # the premise: hundreds of frames were still running when at most a quarter was left
+        hist = np.bincount(iters, minlength=max_iter + 1)
+        left_after = 4096 - np.cumsum(hist)                   # frames running after round r
+        assert ((left_after >= 128) & (left_after <= 1024)).any(), (msg, hist)
+        assert st["frame_rounds"] < 0.95 * fr_ref, (msg, st["frame_rounds"], fr_ref)
+        kb = k_ // 8
+        for f in pick:
+            o = oracle.decode(ogg, yy[f:f + 1], "ms", max_iter=max_iter, msg_f16=(msg == "f16"))
+            assert np.array_equal(out[f * kb:(f + 1) * kb], o["out"]) and iters[f] == o["iters"][0], (msg, f)
+
+
 def test_cpp_coder_at_the_reference_constructible_full_size(built, tmp_path):
     """The largest code the reference's own constructor can make at this length:
     Coder(32400, 64800, rate_1_2) -- z = 2700, E = 205200 (tests/golden/graph_facts.npz) -- through
