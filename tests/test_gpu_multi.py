@@ -305,3 +305,38 @@ def test_staged_input_with_any_number_of_copy_threads(built, threads):
         _lib.check(_lib.load().ldpc_decode(dec._h, y.ctypes.data, 1000, short.ctypes.data, 1000, None))
         assert np.array_equal(short, ref[0][:1000])
         dec.close()
+
+
+def test_host_path_randomized(built):
+    """Seeded random walk over the host-buffer entry point: frame counts, launch-group sizes (groups above and below the
+    4 MiB limit, one to many groups), both input modes, device lists, copy-thread counts, polling, unaligned input
+    buffers -- every result against one reference decode of the whole stream; nothing page-locked is left behind."""
+    g, og, K, M, z = _graph(codes.RATE_1_2, 2304)
+    total = 3000
+    big = np.empty(total * 2304 + 16, np.float32)
+    ref_dec = L.Decoder(g, K, max_batch=total, algo="ms", max_iter=10, tune={"fused": False, "ldsp": False})
+    y0 = channel.awgn_frames(2304, 0, total, 0.85, seed=65)
+    want_out, want_it = ref_dec.decode(y0)
+    ref_dec.close()
+    sample = oracle.decode(og, y0[:32], "ms", max_iter=10)
+    assert np.array_equal(want_out[:32 * K // 8], sample["out"]) and np.array_equal(want_it[:32], sample["iters"])
+    rng = np.random.default_rng(2026)
+    kb = K // 8
+    for case in range(36):
+        off = int(rng.integers(0, 16))                       # the buffer starts 4 * off bytes into its allocation
+        y = big[off:off + total * 2304].reshape(total, 2304)
+        y[:] = y0
+        B = int(rng.choice([1, 7, 64, 300, 455, 456, 1000, 1500, 3000]))
+        devs = [None, None, [0, 0], [0, 0, 0]][int(rng.integers(0, 4))]
+        mode = ["staged", "lock_pages"][int(rng.integers(0, 2))]
+        dec = L.Decoder(g, K, max_batch=B, algo="ms", max_iter=10, devices=devs, host_input=mode,
+                        host_copy_threads=int(rng.integers(1, 7)), poll_interval=int(rng.choice([0, 2])),
+                        tune={"fused": False, "ldsp": False})
+        for _ in range(2):
+            lo = int(rng.integers(0, total - 1))
+            n = int(rng.integers(1, min(total - lo, 40 * B if B < 64 else total) + 1))
+            out, iters = dec.decode(y[lo:lo + n])
+            assert np.array_equal(out, want_out[lo * kb:(lo + n) * kb]), (case, B, devs, mode, lo, n)
+            assert np.array_equal(iters, want_it[lo:lo + n]), (case, B, devs, mode, lo, n)
+            assert L.capi.host_locked_ranges() == (0, 0)
+        dec.close()
