@@ -900,14 +900,15 @@ int setup_flooding(ldpc_decoder *d, const ldpc_graph *g, size_t TF)
     return plan_launches(d);
 }
 
-/* The column-fused check kernel exists in wide waves (V values per lane, 114 VGPRs) and in narrow
- * waves (1 value per lane, 48 VGPRs).  Which one is faster is a property of the box and its power
- * state, not of the code: round 1 found narrow ahead by 2 % on its slow boxes, round 2's boxes run
- * wide 10-17 % faster (profiles/r02_ab_link_wide.txt).  Unless the caller fixes the choice
- * (LDPC_TUNE_LINK_NARROW), a decoder with more than one frame per lane therefore times the forms on its
- * own arrays when it is created -- interleaved launches, a few milliseconds -- and keeps the fastest
- * (wide also wins at 256 ... 1024 frames: +4 ... +8 % on the whole decode).  The arrays hold
- * zeros, which the first decode overwrites; results do not depend on the choice (the tests run both). */
+/* The column-fused check kernel exists in wide waves (V values per lane, 128 VGPRs), in narrow waves (1 value per
+ * lane, 46 VGPRs) and, for tiles of 256 frames, with 2 values per lane (68 VGPRs).  Which one is fastest was
+ * different from box to box in rounds 1 and 2 (narrow ahead by 2 % on round 1's boxes, wide 6-17 % ahead on round
+ * 2's: profiles/r02_ab_link_wide.txt) -- part of which was the placement effect the search below deals with: the
+ * forms do not slow down by the same factor on a slow pair of allocations.  Unless the caller fixes the choice
+ * (LDPC_TUNE_LINK_NARROW / LINK_HALF), a decoder with more than one frame per lane therefore times the forms on
+ * its own arrays when it is created -- interleaved launches, a few milliseconds -- and keeps the fastest (wide
+ * also wins at 256 ... 1024 frames: +4 ... +8 % on the whole decode).  The arrays hold zeros, which the first
+ * decode overwrites; results do not depend on the choice (the tests run all forms). */
 template <int V> int calibrate_link(ldpc_decoder *d)
 {
     using namespace ldpc;
