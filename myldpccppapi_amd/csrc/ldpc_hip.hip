@@ -994,13 +994,13 @@ template <int V> int time_check_phase(ldpc_decoder *d, float *ms_out)
  * are fast and some slow, with R fixed the same holds for Q, the channel array does not matter
  * (tools/gpu_array_trials.py), and consecutive allocations tend to share their luck.  So a decoder whose arrays are
  * large does not take its first allocations as they come: holding what it has, it tries up to `tune_place`
- * (default 5) fresh allocations for R, then for Q, times one whole check phase with each, keeps the fastest and
- * releases the rest at the end; a stage stops as soon as it has seen both speeds (a candidate at least 6 % faster
- * than another).  About 10 ms and 4 GB per candidate while the decoder is being created. */
+ * (default 6) fresh allocations for R, then for Q, times one whole check phase with each, keeps the fastest and
+ * releases the rest at the end; a stage stops as soon as it has seen the fast speed next to the slow one (a
+ * candidate at least 14 % faster than another).  No guarantee: in some processes every pair is slow.  About 10 ms and 4 GB per candidate while the decoder is being created. */
 template <int V> int placement_search(ldpc_decoder *d, size_t TF)
 {
     const size_t bq = TF * (size_t)d->E * d->msg_size, bc = TF * d->N * d->msg_size;
-    const int want = d->tune.place == 0 ? (2 * bq + bc >= ((size_t)256 << 20) ? 5 : 1) : d->tune.place;
+    const int want = d->tune.place == 0 ? (2 * bq + bc >= ((size_t)256 << 20) ? 6 : 1) : d->tune.place;
     if (want <= 1) return LDPC_OK;
     float best_ms = 0.0f;
     int rc = time_check_phase<V>(d, &best_ms);
@@ -1013,7 +1013,8 @@ template <int V> int placement_search(ldpc_decoder *d, size_t TF)
     for (int stage = 0; stage < 2; ++stage) {
         DevBuf<uint8_t> &arr = stage == 0 ? d->R : d->Q;
         for (int c = 1; c < want; ++c) {
-            if (lo < 0.94f * hi && best_ms <= lo) break;                 /* both speeds seen, the fast one is kept */
+            /* three speeds occur (about 1 : 0.88 : 0.83): stop once the fastest of them has been seen next to the slowest */
+            if (lo < 0.86f * hi && best_ms <= lo) break;
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * bq + ((size_t)2 << 30)) break;
             DevBuf<uint8_t> cand;
