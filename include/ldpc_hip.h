@@ -282,8 +282,8 @@ int ldpc_decoder_link_form(ldpc_decoder *d, int32_t *form, int32_t *calibrated, 
 
 /* The placement search of tune_place: how many combinations were timed (*candidates, 0 = no search; the first is the
  * decoder's original allocations, then fresh R arrays, then fresh Q arrays), which was kept (*kept) and the time of one
- * check phase with each (ms[0 .. *candidates), at most 8 are reported). */
-int ldpc_decoder_placement(ldpc_decoder *d, int32_t *candidates, int32_t *kept, float ms[8]);
+ * check phase with each (ms[0 .. *candidates), at most 15). */
+int ldpc_decoder_placement(ldpc_decoder *d, int32_t *candidates, int32_t *kept, float ms[16]);
 /* Measurement aid: device addresses of a streaming decoder's arrays, out[0..3] = Q, R, channel term, hard-bit masks. */
 int ldpc_decoder_array_addresses(ldpc_decoder *d, uint64_t out[4]);
 

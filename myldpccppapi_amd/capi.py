@@ -236,7 +236,7 @@ class Decoder:
         """The creation-time placement search: per candidate set of arrays the column-fused check kernel's time per
         launch, and which one was kept (None: no search was made)."""
         n, kept = ctypes.c_int32(0), ctypes.c_int32(0)
-        ms = (ctypes.c_float * 8)()
+        ms = (ctypes.c_float * 16)()
         _lib.check(_lib.load().ldpc_decoder_placement(self._h, ctypes.byref(n), ctypes.byref(kept), ms))
         if n.value == 0:
             return None

@@ -212,7 +212,7 @@ struct ldpc_decoder {
     float link_cal_ms[3] = {0, 0, 0};   /* what the calibration measured per launch: [0] wide, [1] narrow, [2] half */
     /* placement search (cfg.tune_place): the column-fused check kernel's time on each candidate set of arrays */
     int place_candidates = 0, place_kept = 0;
-    float place_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float place_ms[16] = {};            /* the original pair, then up to 7 fresh R and 7 fresh Q allocations */
     int link_rpw = 16;                  /* rows per wave of the fused check kernel; 0 = fusion off */
     int tune_link_guided = 0;           /* tri-state: shorter row chunks at the end of the fused check launch */
     int tune_tiles_first = 0;           /* tri-state: flooding launches as (tiles, blocks) grids (flood_grid) */
@@ -1023,7 +1023,7 @@ template <int V> int placement_search(ldpc_decoder *d, size_t TF)
             float ms = 0.0f;
             rc = time_check_phase<V>(d, &ms);
             if (rc) return rc;
-            if (d->place_candidates < 8) d->place_ms[d->place_candidates] = ms;
+            if (d->place_candidates < 16) d->place_ms[d->place_candidates] = ms;
             lo = std::min(lo, ms); hi = std::max(hi, ms);
             if (ms < best_ms) {
                 best_ms = ms;
@@ -1035,7 +1035,6 @@ template <int V> int placement_search(ldpc_decoder *d, size_t TF)
             held.push_back(std::move(cand));
         }
     }
-    if (d->place_candidates > 8) d->place_candidates = 8;               /* what place_ms[] can report */
     return LDPC_OK;                                                      /* `held` releases the losers here */
 }
 
@@ -1986,13 +1985,13 @@ int ldpc_decoder_link_form(ldpc_decoder *d, int32_t *form, int32_t *calibrated, 
     return LDPC_OK;
 }
 
-int ldpc_decoder_placement(ldpc_decoder *d, int32_t *candidates, int32_t *kept, float ms[8])
+int ldpc_decoder_placement(ldpc_decoder *d, int32_t *candidates, int32_t *kept, float ms[16])
 {
     if (!d) return fail(LDPC_ERR_ARG, "decoder is NULL");
     if (!d->shards.empty()) return ldpc_decoder_placement(d->shards[0], candidates, kept, ms);
     if (candidates) *candidates = d->place_candidates;
     if (kept) *kept = d->place_kept;
-    if (ms) for (int k = 0; k < 8; ++k) ms[k] = k < d->place_candidates ? d->place_ms[k] : 0.0f;
+    if (ms) for (int k = 0; k < 16; ++k) ms[k] = k < d->place_candidates ? d->place_ms[k] : 0.0f;
     return LDPC_OK;
 }
 
