@@ -129,7 +129,7 @@ typedef struct ldpc_decoder_config {
     int32_t tune_ldsp_grid;     /* record kernels (ldsp_kernels.hpp): persistent workgroups        */
     int32_t tune_ldsp_shape;    /* workgroups per CU | waves per workgroup << 8                    */
     int32_t tune_place;         /* streaming flooding decoders: fresh allocations tried for the check->variable and for
-                                   the variable->check array when the decoder is created (one check phase is timed with
+                                   the variable->check array when the decoder is created (one message round is timed with
                                    each; the fastest combination is kept, the others are released).  WHICH allocations
                                    lie behind these two arrays decides between speeds of the streaming check kernel that
                                    differ by up to 19 % and last as long as the allocations.
@@ -282,7 +282,7 @@ int ldpc_decoder_link_form(ldpc_decoder *d, int32_t *form, int32_t *calibrated, 
 
 /* The placement search of tune_place: how many combinations were timed (*candidates, 0 = no search; the first is the
  * decoder's original allocations, then fresh R arrays, then fresh Q arrays), which was kept (*kept) and the time of one
- * check phase with each (ms[0 .. *candidates), at most 15). */
+ * message round with each (ms[0 .. *candidates), at most 15). */
 int ldpc_decoder_placement(ldpc_decoder *d, int32_t *candidates, int32_t *kept, float ms[16]);
 /* Measurement aid: device addresses of a streaming decoder's arrays, out[0..3] = Q, R, channel term, hard-bit masks. */
 int ldpc_decoder_array_addresses(ldpc_decoder *d, uint64_t out[4]);

@@ -487,6 +487,41 @@ template <int V> int enqueue_check_phase(ldpc_decoder *d, hipStream_t s, int til
     return LDPC_OK;
 }
 
+/* The variable-node phase of round `it`: bits_i = hard(R_i); Q_i = var(R_i) unless this is the last round. */
+template <int V> int enqueue_var_phase(ldpc_decoder *d, hipStream_t s, int tiles, int64_t frames, int it, int max_iter,
+                                       bool fat, const ldpc::TailRef &tr)
+{
+    using namespace ldpc;
+    constexpr int kIdleFat = 8;
+    const int64_t msz = d->msg_size;
+    /* var_i: bits_i = hard(R_i); Q_i = var(R_i) unless this is the last round */
+    const int wq = (it < max_iter) ? 1 : 0;
+    for (auto &g : d->var_groups) {
+        int64_t units = 0;          /* messages read + written + channel values read, per frame */
+        for (int i : g.members) units += (int64_t)((wq ? 2 : 1) * d->col_classes[i].degree + 1) * d->col_classes[i].count;
+        HIP_TRY(span_begin(d, s, 6, g.hi, msz * units * frames, -1, g.lo));
+        VarArgs a{d->R.p, d->Q.p, d->chan.p, d->hard.p, d->done.p, nullptr, nullptr,
+                  d->E, d->N, 0, (d->tune_cpw ? d->tune_cpw : 1) * (fat ? kIdleFat : 1), wq, 0, tr};
+        const dim3 grid = flood_grid(d, fat ? g.blocks_fat : g.blocks, tiles, &a.tiles_first);
+        d->var_group_fn[g.bucket]<<<grid, kBlock, 0, s>>>(a, fat ? g.table_fat.p : g.table.p, (int)g.members.size());
+        HIP_TRY(span_end(d, s));
+    }
+    for (int ci : d->var_solo) {
+        ColClass &cc = d->col_classes[ci];
+        HIP_TRY(span_begin(d, s, 1, cc.degree, msz * ((wq ? 2 : 1) * cc.degree + 1) * cc.count * frames));
+        VarArgs a{d->R.p, d->Q.p, d->chan.p, d->hard.p, d->done.p, cc.col.p, cc.edge.p,
+                  d->E, d->N, cc.count, 1, wq, cc.degree, tr};
+        const int cpw = (d->tune_cpw ? d->tune_cpw : 1) * (fat ? kIdleFat : 1);
+        a.cols_per_wave = cpw;
+        const int slotk = cc.degree <= kMaxUnrolledDegree ? cc.degree : 0;
+        const int waves = (cc.count + cpw - 1) / cpw;
+        const dim3 grid = flood_grid(d, (waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles, &a.tiles_first);
+        d->var_fn[slotk]<<<grid, kBlock, 0, s>>>(a);
+        HIP_TRY(span_end(d, s));
+    }
+    return LDPC_OK;
+}
+
 /* Hand the `count` frames that are still running after round `it` over to the child decoder, let it
  * finish them (rounds it+1 ...), and bring their bits, iteration counts and converged flags back. */
 template <int V> int compact_and_finish(ldpc_decoder *d, int64_t frames, int count, int it, hipStream_t s)
@@ -603,30 +638,9 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
             const int rcp = enqueue_check_phase<V>(d, s, tiles, frames, it, max_iter, fat, tr);
             if (rcp) return rcp;
         }
-        /* var_i: bits_i = hard(R_i); Q_i = var(R_i) unless this is the last round */
-        const int wq = (it < max_iter) ? 1 : 0;
-        for (auto &g : d->var_groups) {
-            int64_t units = 0;          /* messages read + written + channel values read, per frame */
-            for (int i : g.members) units += (int64_t)((wq ? 2 : 1) * d->col_classes[i].degree + 1) * d->col_classes[i].count;
-            HIP_TRY(span_begin(d, s, 6, g.hi, msz * units * frames, -1, g.lo));
-            VarArgs a{d->R.p, d->Q.p, d->chan.p, d->hard.p, d->done.p, nullptr, nullptr,
-                      d->E, d->N, 0, (d->tune_cpw ? d->tune_cpw : 1) * (fat ? kIdleFat : 1), wq, 0, tr};
-            const dim3 grid = flood_grid(d, fat ? g.blocks_fat : g.blocks, tiles, &a.tiles_first);
-            d->var_group_fn[g.bucket]<<<grid, kBlock, 0, s>>>(a, fat ? g.table_fat.p : g.table.p, (int)g.members.size());
-            HIP_TRY(span_end(d, s));
-        }
-        for (int ci : d->var_solo) {
-            ColClass &cc = d->col_classes[ci];
-            HIP_TRY(span_begin(d, s, 1, cc.degree, msz * ((wq ? 2 : 1) * cc.degree + 1) * cc.count * frames));
-            VarArgs a{d->R.p, d->Q.p, d->chan.p, d->hard.p, d->done.p, cc.col.p, cc.edge.p,
-                      d->E, d->N, cc.count, 1, wq, cc.degree, tr};
-            const int cpw = (d->tune_cpw ? d->tune_cpw : 1) * (fat ? kIdleFat : 1);
-            a.cols_per_wave = cpw;
-            const int slotk = cc.degree <= kMaxUnrolledDegree ? cc.degree : 0;
-            const int waves = (cc.count + cpw - 1) / cpw;
-            const dim3 grid = flood_grid(d, (waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles, &a.tiles_first);
-            d->var_fn[slotk]<<<grid, kBlock, 0, s>>>(a);
-            HIP_TRY(span_end(d, s));
+        {
+            const int rcv = enqueue_var_phase<V>(d, s, tiles, frames, it, max_iter, fat, tr);
+            if (rcv) return rcv;
         }
         launched = it;
         /* syndrome of bits_i, then freeze the frames that are clean (iters = i) */
@@ -955,7 +969,8 @@ template <int V> int calibrate_link(ldpc_decoder *d)
     return LDPC_OK;
 }
 
-/* One whole check phase over all tiles of the decoder on zeroed arrays, best of three timed launches (ms). */
+/* One message round (check phase + variable-node phase) over all tiles of the decoder on zeroed arrays, best of three
+ * timed repetitions (ms). */
 template <int V> int time_check_phase(ldpc_decoder *d, float *ms_out)
 {
     hipStream_t s = d->stream;
@@ -971,6 +986,8 @@ template <int V> int time_check_phase(ldpc_decoder *d, float *ms_out)
     for (int rep = 0; rep < 4 && err == hipSuccess && rc == LDPC_OK; ++rep) {
         err = hipEventRecord(ev[0], s);
         rc = enqueue_check_phase<V>(d, s, d->T, (int64_t)d->T * d->F, 1, d->cfg.max_iter, false, ldpc::TailRef{nullptr, 0, 0});
+        if (rc == LDPC_OK)
+            rc = enqueue_var_phase<V>(d, s, d->T, (int64_t)d->T * d->F, 1, d->cfg.max_iter, false, ldpc::TailRef{nullptr, 0, 0});
         if (err == hipSuccess) err = hipEventRecord(ev[1], s);
         if (err == hipSuccess) err = hipEventSynchronize(ev[1]);
         float ms = 0;
@@ -994,9 +1011,10 @@ template <int V> int time_check_phase(ldpc_decoder *d, float *ms_out)
  * are fast and some slow, with R fixed the same holds for Q, the channel array does not matter
  * (tools/gpu_array_trials.py), and consecutive allocations tend to share their luck.  So a decoder whose arrays are
  * large does not take its first allocations as they come: holding what it has, it tries up to `tune_place`
- * (default 6) fresh allocations for R, then for Q, times one whole check phase with each, keeps the fastest and
+ * (default 6) fresh allocations for R, then for Q, times one message round (check + variable-node phase) with each,
+ * keeps the fastest and
  * releases the rest at the end; a stage stops as soon as it has seen the fast speed next to the slow one (a
- * candidate at least 14 % faster than another).  No guarantee: in some processes every pair is slow.  About 10 ms and 4 GB per candidate while the decoder is being created. */
+ * candidate at least 9 % faster than another).  No guarantee: in some processes every pair is slow.  About 10 ms and 4 GB per candidate while the decoder is being created. */
 template <int V> int placement_search(ldpc_decoder *d, size_t TF)
 {
     const size_t bq = TF * (size_t)d->E * d->msg_size, bc = TF * d->N * d->msg_size;
@@ -1013,8 +1031,9 @@ template <int V> int placement_search(ldpc_decoder *d, size_t TF)
     for (int stage = 0; stage < 2; ++stage) {
         DevBuf<uint8_t> &arr = stage == 0 ? d->R : d->Q;
         for (int c = 1; c < want; ++c) {
-            /* three speeds occur (about 1 : 0.88 : 0.83): stop once the fastest of them has been seen next to the slowest */
-            if (lo < 0.86f * hi && best_ms <= lo) break;
+            /* three speeds of the check phase occur (about 1 : 0.88 : 0.83, i.e. 1 : 0.93 : 0.895 for the whole round):
+             * stop once the fastest of them has been seen next to the slowest */
+            if (lo < 0.91f * hi && best_ms <= lo) break;
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * bq + ((size_t)2 << 30)) break;
             DevBuf<uint8_t> cand;
