@@ -48,6 +48,10 @@
 #include "tune.hpp"
 #include "host_stage.hpp"
 
+#ifndef LDPC_IDLE_FAT
+#define LDPC_IDLE_FAT 8
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -161,6 +165,9 @@ struct ClassGroup {
     std::vector<int> members;             /* indices into row_classes / col_classes */
     DevBuf<ldpc::GroupClass> table, table_fat;
 };
+
+/* rounds that are probably idle (the idle hint of run_flooding) launch this many times the rows / columns per wave */
+constexpr int kIdleFat = LDPC_IDLE_FAT;
 
 struct TimedSpan {
     hipEvent_t a, b;
@@ -435,7 +442,6 @@ template <int V> int enqueue_check_phase(ldpc_decoder *d, hipStream_t s, int til
                                          bool fat, const ldpc::TailRef &tr)
 {
     using namespace ldpc;
-    constexpr int kIdleFat = 8;
     const int64_t msz = d->msg_size;
     for (auto &rc : d->row_classes) {
         if (!rc.linked) continue;
@@ -492,7 +498,6 @@ template <int V> int enqueue_var_phase(ldpc_decoder *d, hipStream_t s, int tiles
                                        bool fat, const ldpc::TailRef &tr)
 {
     using namespace ldpc;
-    constexpr int kIdleFat = 8;
     const int64_t msz = d->msg_size;
     /* var_i: bits_i = hard(R_i); Q_i = var(R_i) unless this is the last round */
     const int wq = (it < max_iter) ? 1 : 0;
@@ -602,7 +607,6 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
         }
     }
     const int idle_after = (freeze && !resume && !d->tap_iter && d->cfg.poll_interval == 0) ? d->idle_after : 0;
-    constexpr int kIdleFat = 8;
     /* device-side tail: only when the call has clearly more tiles than the overflow area */
     const bool use_tail = d->tail_enabled && freeze && !resume && !d->tap_iter && tiles >= 4 * d->TO;
     const TailRef tr{use_tail ? d->tail_state.p : nullptr, d->T, d->TO};
@@ -855,7 +859,7 @@ int plan_launches(ldpc_decoder *d)
         ClassGroup &g = groups.back();
         g.bucket = bucket; g.lo = lo; g.hi = hi; g.members = members;
         std::vector<GroupClass> tab, tabf;
-        constexpr int fatk = 8;                       /* = kIdleFat of run_flooding */
+        constexpr int fatk = kIdleFat;
         for (int i : members) {
             GroupClass gc{};
             if (rows) {
