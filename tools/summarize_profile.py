@@ -60,7 +60,7 @@ if stats:
                      r["Percentage"], r["MinNs"], r["MaxNs"]])
     with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras (MI355X, 1 GPU)"])
+        w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras (MI355X, 1 GPU; the decoder's creation-time timings -- forms and placement candidates, about 50 launches of the check kernel and 45 of each variable-node kernel on zeroed arrays -- are in the counts)"])
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         w.writerows(rows)
 
