@@ -340,3 +340,22 @@ def test_host_path_randomized(built):
             assert np.array_equal(iters, want_it[lo:lo + n]), (case, B, devs, mode, lo, n)
             assert L.capi.host_locked_ranges() == (0, 0)
         dec.close()
+
+
+def test_cpp_coder_host_input_modes(built, tmp_path):
+    """Coder::setHostInput: the reference's round trip (Test.cpp) with the caller's postCode staged through the library's
+    pinned ring (default) and page-locked in place (opt-in), in several launch groups (1100 frames of 9216 B x 1024 per
+    group = 9.4 MB groups): identical decoded bytes."""
+    exe = str(tmp_path / "coder_roundtrip")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "coder_roundtrip.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "myldpccppapi_amd"), "-lmyldpc", "-lldpc_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "myldpccppapi_amd")])
+    outs = []
+    for mode in ("0", "1", "2"):
+        pre = str(tmp_path / ("h" + mode))
+        cmd = [exe, "0", "2304", str(1100 * 144), "1024", "2.6", "MS", "11", "--dump", pre, "--host-input", mode]
+        out = subprocess.run(cmd, capture_output=True, text=True)
+        assert out.returncode == 0 and "ParityFail=0" in out.stdout, out.stdout + out.stderr
+        outs.append(open(pre + ".out", "rb").read())
+    assert outs[0] == outs[1] == outs[2]
