@@ -559,7 +559,10 @@ template <int V> int compact_and_finish(ldpc_decoder *d, int64_t frames, int cou
             compact_gather_kernel<V, float><<<gn, kBlock, 0, s>>>((const float *)d->chan.p, (float *)c->chan.p, d->cmap.p, count, d->N);
         }
     }
-    compact_hard_kernel<V><<<gn, kBlock, 0, s>>>(d->hard.p, c->hard.p, d->cmap.p, count, d->N, 0);
+    /* the hard bits travel only where the next decision can depend on the previous one: the sum-product rule keeps the old
+     * bit on a tie or a NaN (decodeCL.c:78-82); min-sum decides every bit anew in every round (bit = !(p > 0), :161-165) */
+    if (d->cfg.algo == LDPC_ALGO_SP) compact_hard_kernel<V><<<gn, kBlock, 0, s>>>(d->hard.p, c->hard.p, d->cmap.p, count, d->N, 0);
+    else HIP_TRY(hipMemsetAsync(c->hard.p, 0, (size_t)ct * d->N * sizeof(uint64_t), s));
     compact_child_state_kernel<0><<<ct, 64, 0, s>>>(c->done.p, c->iters.p, count, d->cfg.max_iter);
     HIP_TRY(hipGetLastError());
     c->timing = false;
