@@ -1418,14 +1418,19 @@ template <int V> __global__ __launch_bounds__(kBlock) void compact_list_kernel(c
     if (slot < capacity) map[slot] = (int32_t)f;
 }
 
+/* The child's tiles hold cf = 64 * cv frames (cv = 1, or 4 for the 1024-frame child of large batches); slot j of the
+ * hand-over is frame j % cf of child tile j / cf, i.e. element j % cf of a row's segment and bit (j % cf) / cv of mask
+ * word (j % cf) % cv. */
+__host__ __device__ inline size_t child_elem(int j, int cf, int64_t rows, int64_t i) { return ((size_t)(j / cf) * rows + i) * cf + (j % cf); }
+
 /* dst[i][j] = src[tile(map[j])][i][position of map[j]] for j < count (0 beyond): the per-edge /
- * per-column values of the running frames, gathered into a V = 1 tile.  One wave per row i. */
+ * per-column values of the running frames, gathered into the child's tiles.  One wave per row i and 64 slots. */
 template <int V, typename T>
 __global__ __launch_bounds__(kBlock) void compact_gather_kernel(const T *__restrict__ src, T *__restrict__ dst,
-                                                                const int32_t *__restrict__ map, int32_t count, int64_t rows)
+                                                                const int32_t *__restrict__ map, int32_t count, int64_t rows, int cf)
 {
     constexpr int F = 64 * V;
-    const int j = threadIdx.x & 63, ct = blockIdx.y, jg = ct * 64 + j;      /* child tile ct, slot jg */
+    const int j = threadIdx.x & 63, jg = blockIdx.y * 64 + j;               /* slot jg */
     const int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + wave_id_in_block();
     if (i >= rows) return;
     T val = (T)0;
@@ -1433,7 +1438,7 @@ __global__ __launch_bounds__(kBlock) void compact_gather_kernel(const T *__restr
         const int64_t f = map[jg];
         val = src[((f / F) * rows + i) * F + (f % F)];
     }
-    dst[((size_t)ct * rows + i) * 64 + j] = val;
+    dst[child_elem(jg, cf, rows, i)] = val;
 }
 
 /* The same gather for MANY frames (hundreds, sitting in every tile of the batch): one thread per element as
@@ -1445,13 +1450,13 @@ constexpr int kGatherChunk = 4096;      /* elements staged at a time (16 KB of f
 template <int V, typename T>
 __global__ __launch_bounds__(kBlock) void compact_gather_rows_kernel(const T *__restrict__ src, T *__restrict__ dst,
                                                                      const int32_t *__restrict__ map, int32_t count,
-                                                                     int64_t rows, int32_t tiles)
+                                                                     int64_t rows, int32_t tiles, int cf)
 {
     constexpr int F = 64 * V;
     constexpr int TPC = kGatherChunk / F;               /* parent tiles per chunk */
     __shared__ __attribute__((aligned(16))) T stage[kGatherChunk];
     const int64_t i = blockIdx.x;
-    const int cslots = ((count + 63) / 64) * 64;        /* child slots in use (whole child tiles of 64) */
+    const int cslots = ((count + cf - 1) / cf) * cf;    /* child slots in use (whole child tiles) */
     for (int t0 = 0; t0 < tiles; t0 += TPC) {
         const int nt = min(TPC, tiles - t0);
         /* 16 bytes per lane (a tile's row segment is F * sizeof(T) >= 128 bytes, 16-byte aligned) */
@@ -1463,36 +1468,48 @@ __global__ __launch_bounds__(kBlock) void compact_gather_rows_kernel(const T *__
         for (int j = threadIdx.x; j < cslots; j += kBlock) {
             if (j < count) {
                 const int f = map[j] - t0 * F;
-                if (f >= 0 && f < nt * F) dst[((size_t)(j / 64) * rows + i) * 64 + (j % 64)] = stage[f];
+                if (f >= 0 && f < nt * F) dst[child_elem(j, cf, rows, i)] = stage[f];
             } else if (t0 == 0) {
-                dst[((size_t)(j / 64) * rows + i) * 64 + (j % 64)] = (T)0;
+                dst[child_elem(j, cf, rows, i)] = (T)0;
             }
         }
         __syncthreads();
     }
 }
 
-/* hard bits: child word n = bit j <- parent bit of frame map[j] (gather), and back (scatter; also the
- * iteration counts and the converged flags) */
+/* hard bits: child bit of slot j <- parent bit of frame map[j] (gather), and back (scatter, one atomic per bit: few
+ * frames).  One wave per column n and group g of 64 slots.  Gather with a child of cv frames per lane: the group's slots are
+ * frames (g % cv) * 64 ... + 63 of child tile g / cv, i.e. the 64 / cv-bit field number g % cv of each of its cv mask
+ * words (bit l of word v = frame cv * l + v) -- written as that field alone, no atomics (compress_stride: the bits of the
+ * lanes v, v + cv, ... of the ballot). */
 template <int V> __global__ __launch_bounds__(kBlock) void compact_hard_kernel(uint64_t *__restrict__ parent, uint64_t *__restrict__ child,
                                                                                const int32_t *__restrict__ map, int32_t count, int32_t N,
-                                                                               int scatter)
+                                                                               int scatter, int cv)
 {
     constexpr int F = 64 * V;
-    const int j = threadIdx.x & 63, ct = blockIdx.y, jg = ct * 64 + j;
+    const int cf = 64 * cv;
+    const int j = threadIdx.x & 63, g = blockIdx.y, jg = g * 64 + j;
     const int64_t n = (int64_t)blockIdx.x * kWavesPerBlock + wave_id_in_block();
     if (n >= N) return;
     const int64_t f = jg < count ? map[jg] : 0;
     const int fi = (int)(f % F);
     unsigned long long *word = reinterpret_cast<unsigned long long *>(parent) + ((f / F) * N + n) * V + fi % V;
-    uint64_t *cw = child + (size_t)ct * N + n;                             /* child: V = 1, hard[tile][n] */
     const int l = fi / V;
     if (!scatter) {
         const bool bit = jg < count && ((*word >> l) & 1ull);
-        const uint64_t w = __ballot(bit);
-        if (j == 0) *cw = w;
+        const uint64_t b = __ballot(bit);
+        uint64_t *cw = child + ((size_t)(g / cv) * N + n) * cv;              /* the cv words of child tile g / cv, column n */
+        if (cv == 1) {
+            if (j == 0) cw[0] = b;
+        } else if (cv == 2) {
+            if (j < 2) reinterpret_cast<uint32_t *>(cw + j)[g % 2] = (uint32_t)compress_stride<2>(b >> j);
+        } else {
+            if (j < 4) reinterpret_cast<uint16_t *>(cw + j)[g % 4] = (uint16_t)compress_stride<4>(b >> j);
+        }
     } else if (jg < count) {
-        if ((*cw >> j) & 1ull) atomicOr(word, 1ull << l);
+        const int cfi = jg % cf;
+        const uint64_t cwv = child[((size_t)(jg / cf) * N + n) * cv + cfi % cv];
+        if ((cwv >> (cfi / cv)) & 1ull) atomicOr(word, 1ull << l);
         else atomicAnd(word, ~(1ull << l));
     }
 }
@@ -1514,9 +1531,11 @@ template <int V> __global__ void compact_inverse_kernel(const int32_t *__restric
 
 template <int V> __global__ __launch_bounds__(kBlock) void compact_hard_back_kernel(uint64_t *__restrict__ parent, const uint64_t *__restrict__ child,
                                                                                     const int32_t *__restrict__ inv,
-                                                                                    const unsigned long long *__restrict__ moved, int32_t N)
+                                                                                    const unsigned long long *__restrict__ moved, int32_t N,
+                                                                                    int cv)
 {
     constexpr int F = 64 * V;
+    const int cf = 64 * cv;
     const int n = blockIdx.x * kBlock + threadIdx.x;
     const int tile = blockIdx.y;
     if (n >= N) return;
@@ -1529,35 +1548,42 @@ template <int V> __global__ __launch_bounds__(kBlock) void compact_hard_back_ker
             const int l = __ffsll((unsigned long long)m) - 1;
             m &= m - 1;
             const int j = inv[tile * F + l * V + v];
-            const uint64_t bit = (child[(size_t)(j / 64) * N + n] >> (j % 64)) & 1ull;
+            const int cfi = j % cf;
+            const uint64_t bit = (child[((size_t)(j / cf) * N + n) * cv + cfi % cv] >> (cfi / cv)) & 1ull;
             w = (w & ~(1ull << l)) | (bit << l);
         }
         parent[((size_t)tile * N + n) * V + v] = w;
     }
 }
 
+/* iteration counts and converged flags back; one thread per slot */
 template <int V> __global__ void compact_finish_kernel(uint64_t *__restrict__ parent_done, int32_t *__restrict__ parent_iters,
                                                        const uint64_t *__restrict__ child_done, const int32_t *__restrict__ child_iters,
-                                                       const int32_t *__restrict__ map, int32_t count)
+                                                       const int32_t *__restrict__ map, int32_t count, int cv)
 {
     constexpr int F = 64 * V;
-    const int j = threadIdx.x, ct = blockIdx.x, jg = ct * 64 + j;          /* 64 threads per child tile */
+    const int cf = 64 * cv;
+    const int jg = blockIdx.x * 64 + threadIdx.x;
     if (jg >= count) return;
     const int64_t f = map[jg];
-    const int fi = (int)(f % F);
+    const int fi = (int)(f % F), cfi = jg % cf;
     parent_iters[f] = child_iters[jg];
-    if ((child_done[ct] >> j) & 1ull)
+    if ((child_done[(size_t)(jg / cf) * cv + cfi % cv] >> (cfi / cv)) & 1ull)
         atomicOr(reinterpret_cast<unsigned long long *>(parent_done) + (f / F) * V + fi % V, 1ull << (fi / V));
 }
 
-/* the child's bookkeeping when it takes over `count` running frames: lanes beyond are padding */
+/* the child's bookkeeping when it takes over `count` running frames: slots beyond are padding.  One block of 64
+ * lanes per child tile. */
 template <int kUnused = 0>       /* a template only so that every translation unit may include this header */
-__global__ void compact_child_state_kernel(uint64_t *__restrict__ done, int32_t *__restrict__ iters, int32_t count, int32_t max_iter)
+__global__ void compact_child_state_kernel(uint64_t *__restrict__ done, int32_t *__restrict__ iters, int32_t count, int32_t max_iter, int cv)
 {
-    const int j = threadIdx.x, ct = blockIdx.x, jg = ct * 64 + j;          /* 64 threads per child tile */
-    iters[jg] = max_iter;
-    const uint64_t pad = __ballot(jg >= count);
-    if (j == 0) done[ct] = pad;
+    const int l = threadIdx.x, tile = blockIdx.x, cf = 64 * cv;
+    for (int v = 0; v < cv; ++v) {
+        const int slot = tile * cf + l * cv + v;
+        iters[slot] = max_iter;
+        const uint64_t pad = __ballot(slot >= count);
+        if (l == 0) done[(size_t)tile * cv + v] = pad;
+    }
 }
 
 /* ---- device-side tail: the same hand-over decided and carried out without the host ---------------

@@ -533,52 +533,56 @@ template <int V> int compact_and_finish(ldpc_decoder *d, int64_t frames, int cou
 {
     using namespace ldpc;
     ldpc_decoder *c = d->child;
-    const unsigned ct = (unsigned)((count + 63) / 64);      /* child tiles in use */
+    const int cv = c->V, cf = 64 * cv;                      /* the child's frames per lane and per tile */
+    const unsigned ct = (unsigned)((count + cf - 1) / cf);  /* child tiles in use */
+    const unsigned cg = ct * (unsigned)cv;                  /* ... in groups of 64 slots */
     HIP_TRY(hipMemsetAsync(d->active.p, 0, sizeof(int32_t), s));
     compact_list_kernel<V><<<(unsigned)((frames + kBlock - 1) / kBlock), kBlock, 0, s>>>(d->done.p, frames, d->cmap.p,
                                                                                          d->active.p, d->child_capacity);
-    const dim3 ge((unsigned)((d->E + kWavesPerBlock - 1) / kWavesPerBlock), ct);
-    const dim3 gn((unsigned)((d->N + kWavesPerBlock - 1) / kWavesPerBlock), ct);
+    const dim3 ge((unsigned)((d->E + kWavesPerBlock - 1) / kWavesPerBlock), cg);
+    const dim3 gn((unsigned)((d->N + kWavesPerBlock - 1) / kWavesPerBlock), cg);
     /* many frames: one coalesced pass over the parent's rows through LDS; few: one sector per value */
     const bool rowwise = count >= 128;
     const int ptiles = (int)((frames + 64 * V - 1) / (64 * V));
     if (d->msg_size == 2) {
         if (rowwise) {
-            compact_gather_rows_kernel<V, _Float16><<<(unsigned)d->E, kBlock, 0, s>>>((const _Float16 *)d->Q.p, (_Float16 *)c->Q.p, d->cmap.p, count, d->E, ptiles);
-            compact_gather_rows_kernel<V, _Float16><<<(unsigned)d->N, kBlock, 0, s>>>((const _Float16 *)d->chan.p, (_Float16 *)c->chan.p, d->cmap.p, count, d->N, ptiles);
+            compact_gather_rows_kernel<V, _Float16><<<(unsigned)d->E, kBlock, 0, s>>>((const _Float16 *)d->Q.p, (_Float16 *)c->Q.p, d->cmap.p, count, d->E, ptiles, cf);
+            compact_gather_rows_kernel<V, _Float16><<<(unsigned)d->N, kBlock, 0, s>>>((const _Float16 *)d->chan.p, (_Float16 *)c->chan.p, d->cmap.p, count, d->N, ptiles, cf);
         } else {
-            compact_gather_kernel<V, _Float16><<<ge, kBlock, 0, s>>>((const _Float16 *)d->Q.p, (_Float16 *)c->Q.p, d->cmap.p, count, d->E);
-            compact_gather_kernel<V, _Float16><<<gn, kBlock, 0, s>>>((const _Float16 *)d->chan.p, (_Float16 *)c->chan.p, d->cmap.p, count, d->N);
+            compact_gather_kernel<V, _Float16><<<ge, kBlock, 0, s>>>((const _Float16 *)d->Q.p, (_Float16 *)c->Q.p, d->cmap.p, count, d->E, cf);
+            compact_gather_kernel<V, _Float16><<<gn, kBlock, 0, s>>>((const _Float16 *)d->chan.p, (_Float16 *)c->chan.p, d->cmap.p, count, d->N, cf);
         }
     } else {
         if (rowwise) {
-            compact_gather_rows_kernel<V, float><<<(unsigned)d->E, kBlock, 0, s>>>((const float *)d->Q.p, (float *)c->Q.p, d->cmap.p, count, d->E, ptiles);
-            compact_gather_rows_kernel<V, float><<<(unsigned)d->N, kBlock, 0, s>>>((const float *)d->chan.p, (float *)c->chan.p, d->cmap.p, count, d->N, ptiles);
+            compact_gather_rows_kernel<V, float><<<(unsigned)d->E, kBlock, 0, s>>>((const float *)d->Q.p, (float *)c->Q.p, d->cmap.p, count, d->E, ptiles, cf);
+            compact_gather_rows_kernel<V, float><<<(unsigned)d->N, kBlock, 0, s>>>((const float *)d->chan.p, (float *)c->chan.p, d->cmap.p, count, d->N, ptiles, cf);
         } else {
-            compact_gather_kernel<V, float><<<ge, kBlock, 0, s>>>((const float *)d->Q.p, (float *)c->Q.p, d->cmap.p, count, d->E);
-            compact_gather_kernel<V, float><<<gn, kBlock, 0, s>>>((const float *)d->chan.p, (float *)c->chan.p, d->cmap.p, count, d->N);
+            compact_gather_kernel<V, float><<<ge, kBlock, 0, s>>>((const float *)d->Q.p, (float *)c->Q.p, d->cmap.p, count, d->E, cf);
+            compact_gather_kernel<V, float><<<gn, kBlock, 0, s>>>((const float *)d->chan.p, (float *)c->chan.p, d->cmap.p, count, d->N, cf);
         }
     }
     /* the hard bits travel only where the next decision can depend on the previous one: the sum-product rule keeps the old
      * bit on a tie or a NaN (decodeCL.c:78-82); min-sum decides every bit anew in every round (bit = !(p > 0), :161-165) */
-    if (d->cfg.algo == LDPC_ALGO_SP) compact_hard_kernel<V><<<gn, kBlock, 0, s>>>(d->hard.p, c->hard.p, d->cmap.p, count, d->N, 0);
-    else HIP_TRY(hipMemsetAsync(c->hard.p, 0, (size_t)ct * d->N * sizeof(uint64_t), s));
-    compact_child_state_kernel<0><<<ct, 64, 0, s>>>(c->done.p, c->iters.p, count, d->cfg.max_iter);
+    HIP_TRY(hipMemsetAsync(c->hard.p, 0, (size_t)ct * d->N * cv * sizeof(uint64_t), s));
+    if (d->cfg.algo == LDPC_ALGO_SP) compact_hard_kernel<V><<<gn, kBlock, 0, s>>>(d->hard.p, c->hard.p, d->cmap.p, count, d->N, 0, cv);
+    compact_child_state_kernel<0><<<ct, 64, 0, s>>>(c->done.p, c->iters.p, count, d->cfg.max_iter, cv);
     HIP_TRY(hipGetLastError());
     c->timing = false;
     c->tap_iter = 0;
-    const int rc = run_flooding<1>(c, nullptr, count, nullptr, 0, nullptr, s, it + 1);
+    const int rc = cv == 1 ? run_flooding<1>(c, nullptr, count, nullptr, 0, nullptr, s, it + 1)
+                           : cv == 2 ? run_flooding<2>(c, nullptr, count, nullptr, 0, nullptr, s, it + 1)
+                                     : run_flooding<4>(c, nullptr, count, nullptr, 0, nullptr, s, it + 1);
     if (rc) return rc;
     d->child_ran = true;
     if (rowwise) {
         HIP_TRY(hipMemsetAsync(d->cmoved.p, 0, d->cmoved.n * sizeof(unsigned long long), s));
         compact_inverse_kernel<V><<<(unsigned)((count + 255) / 256), 256, 0, s>>>(d->cmap.p, count, d->cinv.p, d->cmoved.p);
         compact_hard_back_kernel<V><<<dim3((unsigned)((d->N + kBlock - 1) / kBlock), (unsigned)ptiles), kBlock, 0, s>>>(
-            d->hard.p, c->hard.p, d->cinv.p, d->cmoved.p, d->N);
+            d->hard.p, c->hard.p, d->cinv.p, d->cmoved.p, d->N, cv);
     } else {
-        compact_hard_kernel<V><<<gn, kBlock, 0, s>>>(d->hard.p, c->hard.p, d->cmap.p, count, d->N, 1);
+        compact_hard_kernel<V><<<gn, kBlock, 0, s>>>(d->hard.p, c->hard.p, d->cmap.p, count, d->N, 1, cv);
     }
-    compact_finish_kernel<V><<<ct, 64, 0, s>>>(d->done.p, d->iters.p, c->done.p, c->iters.p, d->cmap.p, count);
+    compact_finish_kernel<V><<<(unsigned)((count + 63) / 64), 64, 0, s>>>(d->done.p, d->iters.p, c->done.p, c->iters.p, d->cmap.p, count, cv);
     HIP_TRY(hipGetLastError());
     return LDPC_OK;
 }
@@ -1375,7 +1379,9 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
             if (cfg->early_term && cfg->poll_interval > 0 && d->T > 1 && d->compact_threshold > 0 && !t_creating_child) {
                 ldpc_decoder_config cc = *cfg;
                 cc.max_batch = d->child_capacity;
-                cc.frames_per_lane = 1;
+                /* tiles of 64 frames for the 512-frame child (the last few stragglers of a batch); tiles of 256 for the
+                 * 1024-frame child, which takes over hundreds of frames: dense tiles, 8- / 16-byte accesses */
+                cc.frames_per_lane = (d->child_capacity > ldpc::kCompactCapacity && d->V == 4) ? 4 : 1;
                 cc.layer_rows = 0;                 /* streaming kernels, same arithmetic */
                 cc.tune_compact = -1;
                 t_creating_child = true;

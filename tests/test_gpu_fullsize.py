@@ -367,6 +367,38 @@ def test_hand_over_of_hundreds_of_frames_is_bit_exact(built, code):
             assert np.array_equal(out[f * kb:(f + 1) * kb], o["out"]) and iters[f] == o["iters"][0], (msg, f)
 
 
+def test_sum_product_hand_over_of_hundreds_of_frames_carries_the_hard_bits(built):
+    """The sum-product rule keeps a column's previous bit on a tie or a NaN (decodeCL.c:78-82), so a hand-over to the child
+    must carry the hard bits (min-sum decides anew every round and does not): a (3600, 1800) IRA code with the headline
+    code's kernel set, 4096 frames of which 650 are noisier -- some of them flood with NaN --, polled every round, child
+    with tiles of 256 frames.  All bytes and iteration counts equal an uncompacted run; 96 frames equal the oracle."""
+    Ns, Ks = 3600, 1800
+    rows, cols = codes.dvbs2_profile_edges(Ns, Ks, profile=[(8, 2), (3, 3)])
+    g = L.Graph(rows, cols, Ns - Ks, Ns)
+    og = oracle.Graph(rows, cols, Ns - Ks, Ns, Ks)
+    rng = np.random.default_rng(92)
+    y = channel.awgn_frames(Ns, 0, 4096, 0.50, seed=92)
+    slow = np.sort(rng.choice(4096, 650, replace=False))
+    y[slow] = channel.awgn_frames(Ns, 5000, 650, 0.66, seed=93)
+    ref = L.Decoder(g, Ks, max_batch=4096, algo="sp", max_iter=30, poll_interval=0, tune={"compact": -1, "device_tail": False})
+    out_ref, it_ref = ref.decode(y)
+    fr_ref = ref.stats()["frame_rounds"]
+    ref.close()
+    dec = L.Decoder(g, Ks, max_batch=4096, algo="sp", max_iter=30, poll_interval=1)
+    out, iters = dec.decode(y)
+    st = dec.stats()
+    dec.close()
+    assert np.array_equal(iters, it_ref) and np.array_equal(out, out_ref)
+    left_after = 4096 - np.cumsum(np.bincount(iters, minlength=31))
+    assert ((left_after >= 128) & (left_after <= 1024)).any(), left_after
+    assert st["frame_rounds"] < fr_ref
+    pick = np.r_[slow[:48], np.setdiff1d(np.arange(4096), slow)[:48]]
+    o = oracle.decode(og, y[pick], "sp", max_iter=30)
+    kb = Ks // 8
+    for i, f in enumerate(pick):
+        assert np.array_equal(out[f * kb:(f + 1) * kb], o["out"][i * kb:(i + 1) * kb]) and iters[f] == o["iters"][i], f
+
+
 def test_cpp_coder_at_the_reference_constructible_full_size(built, tmp_path):
     """The largest code the reference's own constructor can make at this length:
     Coder(32400, 64800, rate_1_2) -- z = 2700, E = 205200 (tests/golden/graph_facts.npz) -- through
