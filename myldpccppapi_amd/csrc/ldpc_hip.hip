@@ -1085,7 +1085,8 @@ template <int V> int placement_search(ldpc_decoder *d, size_t TF)
 /* ================================================================== C ABI */
 
 /* set while a decoder creates its tail-compaction child: the child must not create one of its own */
-static thread_local bool t_creating_child = false;
+/* 0 while an ordinary decoder is created, 1 for its hand-over child, 2 for the child's own child */
+static thread_local int t_child_depth = 0;
 
 extern "C" {
 
@@ -1263,7 +1264,7 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
      * LDPC_TUNE_OFF(LDPC_TUNE_DEVICE_TAIL) switches it off. */
     d->TO = (ldpc::kCompactCapacity + d->F - 1) / d->F;
     d->tail_enabled = cfg->early_term && cfg->poll_interval == 0 && ldpc::tune_pick(tune.device_tail, true) &&
-                      (cfg->algo == LDPC_ALGO_SP || cfg->algo == LDPC_ALGO_MS) && d->T >= 4 * d->TO && !t_creating_child;
+                      (cfg->algo == LDPC_ALGO_SP || cfg->algo == LDPC_ALGO_MS) && d->T >= 4 * d->TO && t_child_depth == 0;
     if (!d->tail_enabled) d->TO = 0;
     d->TA = d->T + d->TO;
     const size_t TF = (size_t)d->TA * d->F;
@@ -1355,11 +1356,11 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
             int rc = setup_flooding(d, g, TF);
             if (rc) return rc;
             /* narrow or wide column-fused check kernel: measured here unless the caller says which */
-            if (tune.link_narrow == 0 && tune.link_half == 0 && !tune.link_deep && d->V >= 2 && !t_creating_child) {
+            if (tune.link_narrow == 0 && tune.link_half == 0 && !tune.link_deep && d->V >= 2 && t_child_depth == 0) {
                 rc = d->V == 1 ? calibrate_link<1>(d) : d->V == 2 ? calibrate_link<2>(d) : calibrate_link<4>(d);
                 if (rc) return rc;
             }
-            if (!t_creating_child) {
+            if (t_child_depth == 0) {
                 rc = d->V == 1 ? placement_search<1>(d, TF) : d->V == 2 ? placement_search<2>(d, TF) : placement_search<4>(d, TF);
                 if (rc) return rc;
             }
@@ -1376,17 +1377,20 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
             d->child_capacity = cfg->max_batch >= 4096 ? 2 * ldpc::kCompactCapacity : ldpc::kCompactCapacity;
             d->compact_threshold = d->child_capacity;
             if (tune.compact) d->compact_threshold = tune.compact < 0 ? 0 : std::min(d->child_capacity, tune.compact);
-            if (cfg->early_term && cfg->poll_interval > 0 && d->T > 1 && d->compact_threshold > 0 && !t_creating_child) {
+            /* the 1024-frame child has a 512-frame child of its own (rate 9/10: of the 681 frames handed over after round 5
+             * only 41 still run after round 6, spread over the child's three tiles of 256) */
+            const bool may_have_child = t_child_depth == 0 || (t_child_depth == 1 && cfg->max_batch > ldpc::kCompactCapacity);
+            if (cfg->early_term && cfg->poll_interval > 0 && d->T > 1 && d->compact_threshold > 0 && may_have_child) {
                 ldpc_decoder_config cc = *cfg;
                 cc.max_batch = d->child_capacity;
                 /* tiles of 64 frames for the 512-frame child (the last few stragglers of a batch); tiles of 256 for the
                  * 1024-frame child, which takes over hundreds of frames: dense tiles, 8- / 16-byte accesses */
                 cc.frames_per_lane = (d->child_capacity > ldpc::kCompactCapacity && d->V == 4) ? 4 : 1;
                 cc.layer_rows = 0;                 /* streaming kernels, same arithmetic */
-                cc.tune_compact = -1;
-                t_creating_child = true;
+                cc.tune_compact = d->child_capacity > ldpc::kCompactCapacity ? 0 : -1;   /* the larger child hands over once more */
+                ++t_child_depth;
                 rc = ldpc_decoder_create(g, &cc, &d->child);
-                t_creating_child = false;
+                --t_child_depth;
                 if (rc) return rc;
                 d->child->is_child = true;
                 HIP_TRY(hipSetDevice(cfg->device));
@@ -1950,10 +1954,10 @@ int ldpc_decoder_stats(ldpc_decoder *d, ldpc_decode_stats *st)
     if (!d->use_fused && d->cfg.algo != LDPC_ALGO_LAYERED && d->cfg.algo != LDPC_ALGO_LAYERED_HOST) {
         st->frame_rounds = d->cfg.early_term ? (int64_t)summary[2] * d->F
                                              : (int64_t)d->last_iterations * d->last_tiles * d->F;
-        if (d->child && d->child_ran) {
+        for (const ldpc_decoder *p = d; p->child && p->child_ran; p = p->child) {      /* the child, and the child's child */
             int32_t cs[4] = {0, 0, 0, 0};
-            HIP_TRY(hipMemcpy(cs, d->child->summary.p, sizeof cs, hipMemcpyDeviceToHost));
-            st->frame_rounds += (int64_t)cs[2] * d->child->F;
+            HIP_TRY(hipMemcpy(cs, p->child->summary.p, sizeof cs, hipMemcpyDeviceToHost));
+            st->frame_rounds += (int64_t)cs[2] * p->child->F;
         }
     }
     for (size_t i = 0; i < d->spans_used; ++i) {
