@@ -190,6 +190,12 @@ struct CheckArgs {
     int32_t degree;                      /* generic kernel only */
     TailRef tail;
     int32_t tiles_first = 0;             /* grid is (tiles, blocks) instead of (blocks, tiles): grid_pos() */
+    /* min-sum, round 1 only: the variable->check messages of round 0 are the channel values (decodeInitMS,
+     * decodeCL.c:121: q = y), so they are read from the channel array by column instead of from Q, which the input
+     * transpose then does not have to write at all (a third of its traffic).  nullptr: read Q. */
+    const void *__restrict__ first_chan = nullptr;     /* [T][N][F] */
+    const int32_t *__restrict__ edge_col = nullptr;    /* [E] column of every edge */
+    int32_t N = 0;
 };
 
 /* Where a block stands in the launch.  Blocks are dispatched with blockIdx.x varying fastest: a grid of
@@ -278,11 +284,18 @@ __global__ __launch_bounds__(kBlock) void check_kernel(const CheckArgs a)
     const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + lane_off;
     T *Rt = static_cast<T *>(a.R) + (size_t)tile * (size_t)a.E * F + lane_off;
 
+    const T *Ct = (ALGO == kAlgoMS && a.first_chan)
+                      ? static_cast<const T *>(a.first_chan) + (size_t)tile * (size_t)a.N * F + lane_off : nullptr;
     for (int r = r_begin; r < r_end; ++r) {
         const int e0 = a.cls_e0[r];
         float x[D][W], out[D][W];
+        if (ALGO == kAlgoMS && Ct) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) vload<W>(x[k], Qt + (size_t)(e0 + k) * F);
+            for (int k = 0; k < D; ++k) vload<W>(x[k], Ct + (size_t)a.edge_col[e0 + k] * F);
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) vload<W>(x[k], Qt + (size_t)(e0 + k) * F);
+        }
         if (ALGO == kAlgoSP) check_sp<D, W>(x, out); else check_ms<D, W>(x, out);
 #pragma unroll
         for (int k = 0; k < D; ++k) vstore<W>(Rt + (size_t)(e0 + k) * F, out[k]);
@@ -380,12 +393,17 @@ struct GroupClass {
 };
 
 template <int ALGO, int D, int V, int W, typename T>
-__device__ __forceinline__ void check_rows(const T *Qt, T *Rt, const int32_t *__restrict__ e0s, int r_begin, int r_end)
+__device__ __forceinline__ void check_rows(const T *Qt, T *Rt, const int32_t *__restrict__ e0s, int r_begin, int r_end,
+                                           const T *Ct = nullptr, const int32_t *__restrict__ edge_col = nullptr)
 {
     constexpr size_t F = 64 * V;
     for (int r = r_begin; r < r_end; ++r) {
         const int e0 = e0s[r];
         float x[D][W], out[D][W];
+        if (ALGO == kAlgoMS && Ct) {            /* round 1: q = y, by column (CheckArgs::first_chan) */
+#pragma unroll
+            for (int k = 0; k < D; ++k) vload<W>(x[k], Ct + (size_t)edge_col[e0 + k] * F);
+        } else
 #pragma unroll
         for (int k = 0; k < D; ++k) vload<W>(x[k], Qt + (size_t)(e0 + k) * F);
         if (ALGO == kAlgoSP) check_sp<D, W>(x, out); else check_ms<D, W>(x, out);
@@ -395,16 +413,18 @@ __device__ __forceinline__ void check_rows(const T *Qt, T *Rt, const int32_t *__
 }
 
 template <int ALGO, int V, typename T, int D, int DLO, int W = 1> struct CheckDispatch {
-    static __device__ __forceinline__ void run(int deg, const T *Qt, T *Rt, const int32_t *e0s, int rb, int re)
+    static __device__ __forceinline__ void run(int deg, const T *Qt, T *Rt, const int32_t *e0s, int rb, int re,
+                                               const T *Ct, const int32_t *edge_col)
     {
-        if (deg == D) check_rows<ALGO, D, V, W, T>(Qt, Rt, e0s, rb, re);
-        else CheckDispatch<ALGO, V, T, D - 1, DLO, W>::run(deg, Qt, Rt, e0s, rb, re);
+        if (deg == D) check_rows<ALGO, D, V, W, T>(Qt, Rt, e0s, rb, re, Ct, edge_col);
+        else CheckDispatch<ALGO, V, T, D - 1, DLO, W>::run(deg, Qt, Rt, e0s, rb, re, Ct, edge_col);
     }
 };
 template <int ALGO, int V, typename T, int DLO, int W> struct CheckDispatch<ALGO, V, T, DLO, DLO, W> {
-    static __device__ __forceinline__ void run(int, const T *Qt, T *Rt, const int32_t *e0s, int rb, int re)
+    static __device__ __forceinline__ void run(int, const T *Qt, T *Rt, const int32_t *e0s, int rb, int re,
+                                               const T *Ct, const int32_t *edge_col)
     {
-        check_rows<ALGO, DLO, V, W, T>(Qt, Rt, e0s, rb, re);
+        check_rows<ALGO, DLO, V, W, T>(Qt, Rt, e0s, rb, re, Ct, edge_col);
     }
 };
 
@@ -430,7 +450,9 @@ __global__ __launch_bounds__(kBlock) void check_group_kernel(const CheckArgs a, 
     const size_t lane_off = (size_t)sub * 64 * W + (size_t)lane * W;
     const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + lane_off;
     T *Rt = static_cast<T *>(a.R) + (size_t)tile * (size_t)a.E * F + lane_off;
-    CheckDispatch<ALGO, V, T, DHI, DLO, W>::run(cls[c].degree, Qt, Rt, cls[c].ids, r_begin, r_end);
+    const T *Ct = (ALGO == kAlgoMS && a.first_chan)
+                      ? static_cast<const T *>(a.first_chan) + (size_t)tile * (size_t)a.N * F + lane_off : nullptr;
+    CheckDispatch<ALGO, V, T, DHI, DLO, W>::run(cls[c].degree, Qt, Rt, cls[c].ids, r_begin, r_end, Ct, a.edge_col);
 }
 
 /* checkResult, decodeCL.c:88-108, on the bit masks: one thread per row XORs the
@@ -1340,8 +1362,9 @@ __global__ __launch_bounds__(kBlock) void init_kernel(const InitArgs a)
             }
         }
         vstore<V>(static_cast<T *>(a.chan) + ((size_t)tile * a.N + n) * F + (size_t)lane * V, ch);
-        for (int p = a.col_ptr[n]; p < a.col_ptr[n + 1]; ++p)
-            vstore<V>(static_cast<T *>(a.Q) + ((size_t)tile * (size_t)a.E + (size_t)a.col_edge[p]) * F + (size_t)lane * V, q);
+        if (a.Q)        /* nullptr: round 1's check kernels read the channel values themselves (CheckArgs::first_chan) */
+            for (int p = a.col_ptr[n]; p < a.col_ptr[n + 1]; ++p)
+                vstore<V>(static_cast<T *>(a.Q) + ((size_t)tile * (size_t)a.E + (size_t)a.col_edge[p]) * F + (size_t)lane * V, q);
         if (lane < V) a.hard[((size_t)tile * a.N + n) * V + lane] = 0;
     }
 }

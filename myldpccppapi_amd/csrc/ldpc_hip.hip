@@ -305,6 +305,7 @@ struct ldpc_decoder {
     int64_t last_frames = 0;
     DevBuf<int32_t> summary;            /* [4]: max iters, converged count, tile-rounds that did work (early termination) */
     bool child_ran = false;             /* the tail-compaction child took part in the last call */
+    bool first_round_from_chan = false; /* this call's round 1 reads q = y from the channel array (min-sum) */
     int32_t last_tiles = 0;
 
     /* a handle over several devices (ldpc_decoder_create_multi): one single-device decoder per entry
@@ -473,6 +474,7 @@ template <int V> int enqueue_check_phase(ldpc_decoder *d, hipStream_t s, int til
         for (int i : g.members) edges += (int64_t)d->row_classes[i].degree * d->row_classes[i].count;
         HIP_TRY(span_begin(d, s, 5, g.hi, 2 * msz * edges * frames, -1, g.lo));
         CheckArgs a{d->Q.p, d->R.p, nullptr, d->done.p, d->E, 0, (d->tune_rpw ? d->tune_rpw : 2) * (fat ? kIdleFat : 1), 0, tr};
+        if (it == 1 && d->first_round_from_chan) { a.first_chan = d->chan.p; a.edge_col = d->edge_col.p; a.N = d->N; }
         const dim3 grid = flood_grid(d, fat ? g.blocks_fat : g.blocks, tiles, &a.tiles_first);
         d->check_group_fn[g.bucket]<<<grid, kBlock, 0, s>>>(a, fat ? g.table_fat.p : g.table.p, (int)g.members.size());
         HIP_TRY(span_end(d, s));
@@ -481,6 +483,7 @@ template <int V> int enqueue_check_phase(ldpc_decoder *d, hipStream_t s, int til
         RowClass &rc = d->row_classes[ci];
         HIP_TRY(span_begin(d, s, 0, rc.degree, 2 * msz * rc.degree * rc.count * frames));
         CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree, tr};
+        if (it == 1 && d->first_round_from_chan) { a.first_chan = d->chan.p; a.edge_col = d->edge_col.p; a.N = d->N; }
         const int slotk = rc.degree <= d->max_check_unrolled ? rc.degree : 0;
         const bool narrow = slotk && (!d->tune_check_wide || rc.degree > kMaxUnrolledDegree);
         const int rpw = (d->tune_rpw ? d->tune_rpw : (narrow ? 2 : 1)) * (fat ? kIdleFat : 1);
@@ -625,9 +628,15 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
                       d->E, frames, d->N, tiles, d->T, d->TO * F, std::min(d->compact_threshold, d->TO * F), 0, max_iter};
     }
 
+    /* min-sum whose check phase is made of the unrolled bucket / single-class kernels only: round 1 reads q = y from the
+     * channel array and the input transpose writes no Q (CheckArgs::first_chan); not with a debug tap */
+    bool q_less = d->cfg.algo == LDPC_ALGO_MS && !resume && !d->tap_iter && max_iter > 1 && d->n_extra == 0;
+    for (auto &rc : d->row_classes) if (rc.linked) q_less = false;
+    for (int ci : d->check_solo) if (d->row_classes[ci].degree > d->max_check_unrolled) q_less = false;
+    d->first_round_from_chan = q_less;
     if (!resume) {
         HIP_TRY(span_begin(d, s, 3));
-        InitArgs a{llr_dev, d->chan.p, d->Q.p, d->hard.p, d->col_ptr.p, d->col_edge.p,
+        InitArgs a{llr_dev, d->chan.p, q_less ? nullptr : d->Q.p, d->hard.p, d->col_ptr.p, d->col_edge.p,
                    d->E, frames, d->N, d->cfg.llr_scale};
         dim3 grid((d->N + kInitCols - 1) / kInitCols, tiles);
         d->init_fn<<<grid, kBlock, 0, s>>>(a);
