@@ -47,6 +47,7 @@ namespace ldpc {
 constexpr int kAlgoSP = 0;
 constexpr int kAlgoMS = 1;
 constexpr int kCompactCapacity = 512;   /* frames a child decoder takes over (8 tiles of 64) */
+constexpr int kLastCapacity = 64;       /* ... and the last decoder of the chain: one tile */
 constexpr int kBlock = 256;          /* 4 waves */
 constexpr int kWavesPerBlock = 4;
 constexpr int kMaxUnrolledDegree = 16;       /* variable-node kernels, sum-product check kernels */

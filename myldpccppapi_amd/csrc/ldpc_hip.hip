@@ -304,7 +304,7 @@ struct ldpc_decoder {
     int32_t last_iterations = 0;
     int64_t last_frames = 0;
     DevBuf<int32_t> summary;            /* [4]: max iters, converged count, tile-rounds that did work (early termination) */
-    bool child_ran = false;             /* the tail-compaction child took part in the last call */
+    ldpc_decoder *handed_to = nullptr;  /* the decoder (child, or the child's child) that finished the last call's stragglers */
     bool first_round_from_chan = false; /* this call's round 1 reads q = y from the channel array (min-sum) */
     int32_t last_tiles = 0;
 
@@ -535,8 +535,12 @@ template <int V> int enqueue_var_phase(ldpc_decoder *d, hipStream_t s, int tiles
 template <int V> int compact_and_finish(ldpc_decoder *d, int64_t frames, int count, int it, hipStream_t s)
 {
     using namespace ldpc;
+    /* the smallest decoder of the chain (1024 frames in tiles of 256 -> 512 in tiles of 64 -> one tile of 64) that holds them:
+     * a tile of 256 frames for a dozen stragglers would cost four times the traffic per round, eight tiles of 64 with one
+     * straggler each eight times that of one tile */
     ldpc_decoder *c = d->child;
-    const int cv = c->V, cf = 64 * cv;                      /* the child's frames per lane and per tile */
+    while (c->child && count <= c->child->cfg.max_batch) c = c->child;
+    const int cv = c->V, cf = 64 * cv;                      /* its frames per lane and per tile */
     const unsigned ct = (unsigned)((count + cf - 1) / cf);  /* child tiles in use */
     const unsigned cg = ct * (unsigned)cv;                  /* ... in groups of 64 slots */
     HIP_TRY(hipMemsetAsync(d->active.p, 0, sizeof(int32_t), s));
@@ -576,7 +580,7 @@ template <int V> int compact_and_finish(ldpc_decoder *d, int64_t frames, int cou
                            : cv == 2 ? run_flooding<2>(c, nullptr, count, nullptr, 0, nullptr, s, it + 1)
                                      : run_flooding<4>(c, nullptr, count, nullptr, 0, nullptr, s, it + 1);
     if (rc) return rc;
-    d->child_ran = true;
+    d->handed_to = c;
     if (rowwise) {
         HIP_TRY(hipMemsetAsync(d->cmoved.p, 0, d->cmoved.n * sizeof(unsigned long long), s));
         compact_inverse_kernel<V><<<(unsigned)((count + 255) / 256), 256, 0, s>>>(d->cmap.p, count, d->cinv.p, d->cmoved.p);
@@ -606,7 +610,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
     const bool resume = start_round > 1;    /* a child taking over running frames: their state is in place */
     HIP_TRY(hipMemsetAsync(d->failw.p, 0, d->failw.n * sizeof(uint64_t), s));
     HIP_TRY(hipMemsetAsync(d->summary.p, 0, 4 * sizeof(int32_t), s));
-    d->child_ran = false;
+    d->handed_to = nullptr;
     /* idle hint from the previous call (asynchronous early termination only) */
     if (!resume && d->summary_pending) {
         if (hipEventQuery(d->ev_summary) == hipSuccess) {
@@ -703,7 +707,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
                 if (d->child && running <= d->compact_threshold && (int64_t)running * 4 <= frames && tiles > 1 && !d->tap_iter) {
                     const int rc = compact_and_finish<V>(d, frames, running, it, s);
                     if (rc) return rc;
-                    launched = d->child->last_iterations;
+                    launched = d->handed_to->last_iterations;
                     break;
                 }
             }
@@ -1383,12 +1387,14 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
             /* the child takes over once at most a quarter of the batch still runs: 1024 frames for the 4096-frame
              * batches of the benchmark configurations (rate 9/10, fp16: 681 frames still run after round 5 of 8 and
              * sit in all 16 tiles; a 512-frame child had to wait for round 6), 512 otherwise */
-            d->child_capacity = cfg->max_batch >= 4096 ? 2 * ldpc::kCompactCapacity : ldpc::kCompactCapacity;
+            if (t_child_depth == 0) d->child_capacity = cfg->max_batch >= 4096 ? 2 * ldpc::kCompactCapacity : ldpc::kCompactCapacity;
+            else d->child_capacity = cfg->max_batch > ldpc::kCompactCapacity ? ldpc::kCompactCapacity : ldpc::kLastCapacity;
             d->compact_threshold = d->child_capacity;
             if (tune.compact) d->compact_threshold = tune.compact < 0 ? 0 : std::min(d->child_capacity, tune.compact);
             /* the 1024-frame child has a 512-frame child of its own (rate 9/10: of the 681 frames handed over after round 5
-             * only 41 still run after round 6, spread over the child's three tiles of 256) */
-            const bool may_have_child = t_child_depth == 0 || (t_child_depth == 1 && cfg->max_batch > ldpc::kCompactCapacity);
+             * only 41 still run after round 6, spread over the child's three tiles of 256), and that one a single tile of 64
+             * frames (sum-product at 5 dB: a handful of frames in 4096 run all 50 rounds, one in each of its tiles) */
+            const bool may_have_child = t_child_depth == 0 || cfg->max_batch > ldpc::kLastCapacity;
             if (cfg->early_term && cfg->poll_interval > 0 && d->T > 1 && d->compact_threshold > 0 && may_have_child) {
                 ldpc_decoder_config cc = *cfg;
                 cc.max_batch = d->child_capacity;
@@ -1396,7 +1402,7 @@ int ldpc_decoder_create(const ldpc_graph *g, const ldpc_decoder_config *cfg, ldp
                  * 1024-frame child, which takes over hundreds of frames: dense tiles, 8- / 16-byte accesses */
                 cc.frames_per_lane = (d->child_capacity > ldpc::kCompactCapacity && d->V == 4) ? 4 : 1;
                 cc.layer_rows = 0;                 /* streaming kernels, same arithmetic */
-                cc.tune_compact = d->child_capacity > ldpc::kCompactCapacity ? 0 : -1;   /* the larger child hands over once more */
+                cc.tune_compact = d->child_capacity > ldpc::kLastCapacity ? 0 : -1;     /* all but the last hand over once more */
                 ++t_child_depth;
                 rc = ldpc_decoder_create(g, &cc, &d->child);
                 --t_child_depth;
@@ -1963,10 +1969,10 @@ int ldpc_decoder_stats(ldpc_decoder *d, ldpc_decode_stats *st)
     if (!d->use_fused && d->cfg.algo != LDPC_ALGO_LAYERED && d->cfg.algo != LDPC_ALGO_LAYERED_HOST) {
         st->frame_rounds = d->cfg.early_term ? (int64_t)summary[2] * d->F
                                              : (int64_t)d->last_iterations * d->last_tiles * d->F;
-        for (const ldpc_decoder *p = d; p->child && p->child_ran; p = p->child) {      /* the child, and the child's child */
+        for (const ldpc_decoder *p = d->handed_to; p; p = p->handed_to) {      /* the child, and whom it handed over to */
             int32_t cs[4] = {0, 0, 0, 0};
-            HIP_TRY(hipMemcpy(cs, p->child->summary.p, sizeof cs, hipMemcpyDeviceToHost));
-            st->frame_rounds += (int64_t)cs[2] * p->child->F;
+            HIP_TRY(hipMemcpy(cs, p->summary.p, sizeof cs, hipMemcpyDeviceToHost));
+            st->frame_rounds += (int64_t)cs[2] * p->F;
         }
     }
     for (size_t i = 0; i < d->spans_used; ++i) {
