@@ -77,6 +77,18 @@ __global__ __launch_bounds__(256) void copy_kernel(const vf4 *__restrict__ src, 
     }
 }
 
+__global__ __launch_bounds__(256) void copy_nt_kernel(const vf4 *__restrict__ src, vf4 *__restrict__ dst, size_t n4)
+{
+    const size_t stride = (size_t)gridDim.x * 1024;
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n4; i += stride) {
+        vf4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (i + k * 256 < n4) v[k] = __builtin_nontemporal_load(&src[i + k * 256]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (i + k * 256 < n4) __builtin_nontemporal_store(v[k], &dst[i + k * 256]);
+    }
+}
+
 template <typename F> static float time_ms(F launch, int reps)
 {
     hipEvent_t a, b;
@@ -99,7 +111,7 @@ template <typename F> static float time_ms(F launch, int reps)
     return best;
 }
 
-template <int D, int SEG4, bool NT> static void run(const char *name, vf4 *src, vf4 *dst, vf4 *chan, size_t total_bytes)
+template <int D, int SEG4, bool NT> static void run(const char *name, vf4 *src, vf4 *dst, vf4 *chan, size_t total_bytes, int streams = 0)
 {
     // edges = disjoint segments of the arrays; every column owns D of them, randomly placed
     const size_t seg_bytes = (size_t)SEG4 * 1024;
@@ -109,6 +121,20 @@ template <int D, int SEG4, bool NT> static void run(const char *name, vf4 *src, 
     std::iota(perm.begin(), perm.end(), 0);
     std::mt19937_64 rng(12345);
     std::shuffle(perm.begin(), perm.end(), rng);
+    /* streams = 1: column c's k-th segment is segment c of stream k (D contiguous streams: what a quasi-cyclic code's
+     * column groups would read if the edges were stored group-wise); 2: the same in runs of 360 columns whose bases are
+     * random (360 = the DVB-S2 group size) */
+    if (streams == 1)
+        for (int c = 0; c < n_cols; ++c)
+            for (int k = 0; k < D; ++k) perm[(size_t)c * D + k] = (int32_t)((size_t)k * n_cols + c);
+    if (streams == 2) {
+        const int groups = n_cols / 360;
+        std::vector<int32_t> base((size_t)groups * D);
+        std::iota(base.begin(), base.end(), 0);
+        std::shuffle(base.begin(), base.end(), rng);
+        for (int c = 0; c < groups * 360; ++c)
+            for (int k = 0; k < D; ++k) perm[(size_t)c * D + k] = base[(size_t)(c / 360) * D + k] * 360 + c % 360;
+    }
     int32_t *idx;
     CHECK(hipMalloc((void **)&idx, (size_t)n_cols * D * sizeof(int32_t)));
     CHECK(hipMemcpy(idx, perm.data(), (size_t)n_cols * D * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -141,5 +167,16 @@ int main()
     run<3, 2, true>("gather D=3, 2-KiB segments, nt", src, dst, chan, total);
     run<3, 4, true>("gather D=3, 4-KiB segments, nt", src, dst, chan, total);
     run<8, 4, true>("gather D=8, 4-KiB segments, nt", src, dst, chan, total);
+    run<8, 1, true>("D=8 contiguous streams, nt", src, dst, chan, total, 1);
+    run<8, 1, false>("D=8 contiguous streams, default policy", src, dst, chan, total, 1);
+    run<3, 1, true>("D=3 contiguous streams, nt", src, dst, chan, total, 1);
+    run<8, 1, true>("D=8 runs of 360 segments, nt", src, dst, chan, total, 2);
+    run<8, 1, false>("D=8 runs of 360 segments, default policy", src, dst, chan, total, 2);
+    run<3, 1, true>("D=3 runs of 360 segments, nt", src, dst, chan, total, 2);
+    {
+        const size_t n4 = total / 16;
+        const float ms = time_ms([&] { copy_nt_kernel<<<256 * 64, 256>>>(src, dst, n4); }, 5);
+        printf("%-44s %8.3f ms  %7.1f GB/s\n", "float4 copy, 3 GiB, nt", ms, 2.0 * total / (ms * 1e-3) / 1e9);
+    }
     return 0;
 }
