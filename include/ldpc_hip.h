@@ -143,6 +143,10 @@ typedef struct ldpc_decoder_config {
                                    library's pinned ring (0 = automatic: 4; 1..16).  They belong to the
                                    handle: started on its first large host-buffer call, joined when it is
                                    destroyed                                                           */
+    int32_t tune_q_order;       /* streaming flooding decoders: the variable->check array is stored in the order its
+                                   writers produce it (variable-node kernels column by column), so that every store
+                                   of a round streams and the check kernels gather their inputs instead
+                                   (0 = automatic: on; 1 = on; -1 = off: edge order, as the check->variable array) */
 } ldpc_decoder_config;
 
 /* two-bit fields of tune_flags: LDPC_TUNE_ON(f) forces the choice on, LDPC_TUNE_OFF(f) off */

@@ -35,7 +35,7 @@ class DecoderConfig(ctypes.Structure):
                 ("tune_compact", ctypes.c_int32), ("tune_ldsp_grid", ctypes.c_int32),
                 ("tune_ldsp_shape", ctypes.c_int32), ("tune_place", ctypes.c_int32),
                 ("host_input", ctypes.c_int32),
-                ("host_copy_threads", ctypes.c_int32)]
+                ("host_copy_threads", ctypes.c_int32), ("tune_q_order", ctypes.c_int32)]
 
 
 class DecodeStats(ctypes.Structure):

@@ -22,7 +22,7 @@ ALGOS = {"sp": ALGO_SP, "ms": ALGO_MS, "layered": ALGO_LAYERED, "ms_fused": ALGO
 TUNE_FIELDS = {"fused": 0, "ldsp": 2, "ldsp_ext": 4, "ldsp_pack": 6, "link_narrow": 8, "check_wide": 10,
                "syn_xcd": 12, "fused_pack": 14, "fused_loop": 16, "device_tail": 18, "merge": 20, "link_deep": 22, "link_half": 24,
                "link_guided": 26, "tiles_first": 28}
-TUNE_INTS = ("rows_per_wave", "cols_per_wave", "link_rows", "compact", "ldsp_grid", "ldsp_per_cu", "ldsp_waves", "place")
+TUNE_INTS = ("rows_per_wave", "cols_per_wave", "link_rows", "compact", "ldsp_grid", "ldsp_per_cu", "ldsp_waves", "place", "q_order")
 
 
 def apply_tune(cfg, tune):

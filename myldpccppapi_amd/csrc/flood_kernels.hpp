@@ -197,7 +197,28 @@ struct CheckArgs {
     const void *__restrict__ first_chan = nullptr;     /* [T][N][F] */
     const int32_t *__restrict__ edge_col = nullptr;    /* [E] column of every edge */
     int32_t N = 0;
+    /* Where the variable->check message of edge e lives in Q: slot qpos[e] (nullptr: slot e).  Q is stored in the
+     * order its WRITERS produce it -- the variable-node kernels column by column, then the column-fused check
+     * kernel's own edges row by row -- so that every store of a round streams; the check kernels, which read Q,
+     * gather instead (tools/gather_probe.hip: random 1-KiB reads cost nothing, random writes 9-15 %). */
+    const int32_t *__restrict__ qpos = nullptr;        /* [E]; never null in a launch (the identity where Q is in edge order) */
 };
+
+/* Q slots (CheckArgs::qpos) of the D edges e0 ... of a row: ONE load by the wave's first D lanes and a broadcast each.
+ * The values are wave-uniform, so a message's address is a scalar row address plus the lane's 32-bit offset (the
+ * slots of a row are unrelated: one 64-bit vector address each would cost two registers per message in flight). */
+template <int D> __device__ __forceinline__ void row_slots(const int32_t *__restrict__ qpos, int e0, int lane, int (&slot)[D])
+{
+    static_assert(D <= 64, "one lane per edge");
+    const int mine = qpos[e0 + (lane < D ? lane : D - 1)];
+#pragma unroll
+    for (int k = 0; k < D; ++k) slot[k] = __builtin_amdgcn_readlane(mine, k);
+}
+/* slot of one edge */
+__device__ __forceinline__ int edge_slot(const int32_t *__restrict__ qpos, int e)
+{
+    return __builtin_amdgcn_readfirstlane(qpos[e]);
+}
 
 /* Where a block stands in the launch.  Blocks are dispatched with blockIdx.x varying fastest: a grid of
  * (tiles, blocks) therefore has the blocks in flight at any moment spread over ALL tiles of the batch --
@@ -281,8 +302,8 @@ __global__ __launch_bounds__(kBlock) void check_kernel(const CheckArgs a)
     const int sub = wave % SUB;
     const int r_begin = (wave / SUB) * a.rows_per_wave;
     const int r_end = min(r_begin + a.rows_per_wave, a.n_rows);
-    const size_t lane_off = (size_t)sub * 64 * W + (size_t)lane * W;
-    const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + lane_off;
+    const unsigned lane_off = (unsigned)sub * 64 * W + (unsigned)lane * W;
+    const T *Qu = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F;      /* wave-uniform: + slot * F + lane_off */
     T *Rt = static_cast<T *>(a.R) + (size_t)tile * (size_t)a.E * F + lane_off;
 
     const T *Ct = (ALGO == kAlgoMS && a.first_chan)
@@ -294,8 +315,10 @@ __global__ __launch_bounds__(kBlock) void check_kernel(const CheckArgs a)
 #pragma unroll
             for (int k = 0; k < D; ++k) vload<W>(x[k], Ct + (size_t)a.edge_col[e0 + k] * F);
         } else {
+            int sl[D];
+            row_slots<D>(a.qpos, e0, lane, sl);
 #pragma unroll
-            for (int k = 0; k < D; ++k) vload<W>(x[k], Qt + (size_t)(e0 + k) * F);
+            for (int k = 0; k < D; ++k) vload<W>(x[k], Qu + (size_t)sl[k] * F + lane_off);
         }
         if (ALGO == kAlgoSP) check_sp<D, W>(x, out); else check_ms<D, W>(x, out);
 #pragma unroll
@@ -308,7 +331,8 @@ __global__ __launch_bounds__(kBlock) void check_kernel(const CheckArgs a)
  * the exact left-to-right product needs one pass per output, as the reference does (L1/L2 serve the
  * repeats).  Qt / Rt: this lane's V values of the tile. */
 template <int ALGO, int V, typename T>
-__device__ __forceinline__ void check_row_generic(const T *Qt, T *Rt, int e0, int D)
+__device__ __forceinline__ void check_row_generic(const T *Qu, unsigned lane_off, T *Rt, int e0, int D,
+                                                  const int32_t *__restrict__ qpos)
 {
     constexpr size_t F = 64 * V;
     if (ALGO == kAlgoMS) {
@@ -321,7 +345,7 @@ __device__ __forceinline__ void check_row_generic(const T *Qt, T *Rt, int e0, in
         for (int v = 0; v < V; ++v) { m1[v] = 1000.0f; m2[v] = 1000.0f; idx[v] = -1; par[v] = 0; }
         for (int j = 0; j < D; ++j) {
             float xj[V];
-            vload<V>(xj, Qt + (size_t)(e0 + j) * F);
+            vload<V>(xj, Qu + (size_t)edge_slot(qpos, e0 + j) * F + lane_off);
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 const float m = __builtin_fabsf(xj[v]);
@@ -332,7 +356,7 @@ __device__ __forceinline__ void check_row_generic(const T *Qt, T *Rt, int e0, in
         }
         for (int k = 0; k < D; ++k) {
             float xk[V], o[V];
-            vload<V>(xk, Qt + (size_t)(e0 + k) * F);
+            vload<V>(xk, Qu + (size_t)edge_slot(qpos, e0 + k) * F + lane_off);
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 const float b = (k == idx[v]) ? m2[v] : m1[v];
@@ -351,7 +375,7 @@ __device__ __forceinline__ void check_row_generic(const T *Qt, T *Rt, int e0, in
         for (int j = 0; j < D; ++j) {
             if (j == k) continue;
             float xj[V];
-            vload<V>(xj, Qt + (size_t)(e0 + j) * F);
+            vload<V>(xj, Qu + (size_t)edge_slot(qpos, e0 + j) * F + lane_off);
 #pragma unroll
             for (int v = 0; v < V; ++v) p[v] *= xj[v];
         }
@@ -373,9 +397,9 @@ __global__ __launch_bounds__(kBlock) void check_kernel_generic(const CheckArgs a
     const int wave = gp.block * kWavesPerBlock + wave_id_in_block();
     const int r_begin = wave * a.rows_per_wave;
     const int r_end = min(r_begin + a.rows_per_wave, a.n_rows);
-    const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    const T *Qu = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F;
     T *Rt = static_cast<T *>(a.R) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
-    for (int r = r_begin; r < r_end; ++r) check_row_generic<ALGO, V, T>(Qt, Rt, a.cls_e0[r], a.degree);
+    for (int r = r_begin; r < r_end; ++r) check_row_generic<ALGO, V, T>(Qu, (unsigned)lane * V, Rt, a.cls_e0[r], a.degree, a.qpos);
 }
 
 /* ---- several degree classes in ONE launch -------------------------------------------------
@@ -391,12 +415,15 @@ struct GroupClass {
     int32_t pad;
     const int32_t *ids;         /* rows: first edge ids; columns: column ids */
     const int32_t *edges;       /* columns: [count][degree] edge ids */
+    int64_t q_base;             /* columns: first Q slot of the class (VarArgs::q_base), -1: slot = edge id */
 };
 
 template <int ALGO, int D, int V, int W, typename T>
-__device__ __forceinline__ void check_rows(const T *Qt, T *Rt, const int32_t *__restrict__ e0s, int r_begin, int r_end,
-                                           const T *Ct = nullptr, const int32_t *__restrict__ edge_col = nullptr)
+__device__ __forceinline__ void check_rows(const T *Qu, unsigned lane_off, T *Rt, const int32_t *__restrict__ e0s, int r_begin, int r_end,
+                                           const T *Ct, const int32_t *__restrict__ edge_col,
+                                           const int32_t *__restrict__ qpos)
 {
+    const int lane = threadIdx.x & 63;
     constexpr size_t F = 64 * V;
     for (int r = r_begin; r < r_end; ++r) {
         const int e0 = e0s[r];
@@ -404,9 +431,12 @@ __device__ __forceinline__ void check_rows(const T *Qt, T *Rt, const int32_t *__
         if (ALGO == kAlgoMS && Ct) {            /* round 1: q = y, by column (CheckArgs::first_chan) */
 #pragma unroll
             for (int k = 0; k < D; ++k) vload<W>(x[k], Ct + (size_t)edge_col[e0 + k] * F);
-        } else
+        } else {
+            int sl[D];
+            row_slots<D>(qpos, e0, lane, sl);
 #pragma unroll
-        for (int k = 0; k < D; ++k) vload<W>(x[k], Qt + (size_t)(e0 + k) * F);
+            for (int k = 0; k < D; ++k) vload<W>(x[k], Qu + (size_t)sl[k] * F + lane_off);
+        }
         if (ALGO == kAlgoSP) check_sp<D, W>(x, out); else check_ms<D, W>(x, out);
 #pragma unroll
         for (int k = 0; k < D; ++k) vstore<W>(Rt + (size_t)(e0 + k) * F, out[k]);
@@ -414,18 +444,18 @@ __device__ __forceinline__ void check_rows(const T *Qt, T *Rt, const int32_t *__
 }
 
 template <int ALGO, int V, typename T, int D, int DLO, int W = 1> struct CheckDispatch {
-    static __device__ __forceinline__ void run(int deg, const T *Qt, T *Rt, const int32_t *e0s, int rb, int re,
-                                               const T *Ct, const int32_t *edge_col)
+    static __device__ __forceinline__ void run(int deg, const T *Qu, unsigned lane_off, T *Rt, const int32_t *e0s, int rb, int re,
+                                               const T *Ct, const int32_t *edge_col, const int32_t *qpos)
     {
-        if (deg == D) check_rows<ALGO, D, V, W, T>(Qt, Rt, e0s, rb, re, Ct, edge_col);
-        else CheckDispatch<ALGO, V, T, D - 1, DLO, W>::run(deg, Qt, Rt, e0s, rb, re, Ct, edge_col);
+        if (deg == D) check_rows<ALGO, D, V, W, T>(Qu, lane_off, Rt, e0s, rb, re, Ct, edge_col, qpos);
+        else CheckDispatch<ALGO, V, T, D - 1, DLO, W>::run(deg, Qu, lane_off, Rt, e0s, rb, re, Ct, edge_col, qpos);
     }
 };
 template <int ALGO, int V, typename T, int DLO, int W> struct CheckDispatch<ALGO, V, T, DLO, DLO, W> {
-    static __device__ __forceinline__ void run(int, const T *Qt, T *Rt, const int32_t *e0s, int rb, int re,
-                                               const T *Ct, const int32_t *edge_col)
+    static __device__ __forceinline__ void run(int, const T *Qu, unsigned lane_off, T *Rt, const int32_t *e0s, int rb, int re,
+                                               const T *Ct, const int32_t *edge_col, const int32_t *qpos)
     {
-        check_rows<ALGO, DLO, V, W, T>(Qt, Rt, e0s, rb, re, Ct, edge_col);
+        check_rows<ALGO, DLO, V, W, T>(Qu, lane_off, Rt, e0s, rb, re, Ct, edge_col, qpos);
     }
 };
 
@@ -448,12 +478,12 @@ __global__ __launch_bounds__(kBlock) void check_group_kernel(const CheckArgs a, 
     const int sub = wave % SUB;
     const int r_begin = (wave / SUB) * a.rows_per_wave;
     const int r_end = min(r_begin + a.rows_per_wave, cls[c].count);
-    const size_t lane_off = (size_t)sub * 64 * W + (size_t)lane * W;
-    const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + lane_off;
+    const unsigned lane_off = (unsigned)sub * 64 * W + (unsigned)lane * W;
+    const T *Qu = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F;
     T *Rt = static_cast<T *>(a.R) + (size_t)tile * (size_t)a.E * F + lane_off;
     const T *Ct = (ALGO == kAlgoMS && a.first_chan)
                       ? static_cast<const T *>(a.first_chan) + (size_t)tile * (size_t)a.N * F + lane_off : nullptr;
-    CheckDispatch<ALGO, V, T, DHI, DLO, W>::run(cls[c].degree, Qt, Rt, cls[c].ids, r_begin, r_end, Ct, a.edge_col);
+    CheckDispatch<ALGO, V, T, DHI, DLO, W>::run(cls[c].degree, Qu, lane_off, Rt, cls[c].ids, r_begin, r_end, Ct, a.edge_col, a.qpos);
 }
 
 /* checkResult, decodeCL.c:88-108, on the bit masks: one thread per row XORs the
@@ -548,6 +578,9 @@ struct VarArgs {
     int32_t degree;                       /* generic kernel only */
     TailRef tail;
     int32_t tiles_first = 0;              /* grid is (tiles, blocks): grid_pos() */
+    /* first Q slot of this class (CheckArgs::qpos: Q is stored in the order its writers produce it): column ci of
+     * the class writes its D messages to slots q_base + ci * D ... -- one contiguous run per wave.  -1: slot = edge id. */
+    int64_t q_base = -1;
 };
 
 /* Sum-product variable node: hardDecision (decodeCL.c:72-82) and refreshQ
@@ -645,9 +678,9 @@ __device__ __forceinline__ void link_extra_rows(const CheckArgs &a, const LinkAr
     const int lane = threadIdx.x & 63;
     const int w = (block - g.link_blocks) * kWavesPerBlock + wave_id_in_block();
     if (w >= g.n_extra) return;
-    const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+    const T *Qu = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F;
     T *Rt = static_cast<T *>(a.R) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
-    check_row_generic<ALGO, V, T>(Qt, Rt, g.extra_e0[w], g.extra_deg[w]);
+    check_row_generic<ALGO, V, T>(Qu, (unsigned)lane * V, Rt, g.extra_e0[w], g.extra_deg[w], a.qpos);
 }
 
 /* build-time experiment hook: -DLDPC_LINK_WIDE_WAVES=n asks the compiler for n waves per SIMD */
@@ -669,8 +702,11 @@ __global__ __launch_bounds__(kBlock) LDPC_LINK_WIDE_ATTR void check_link_kernel(
     int r_begin, r_end;
     link_chunk_rows(wave, a.rows_per_wave, g.n_big, g.small_rows, a.n_rows, &r_begin, &r_end);
     const size_t lane_off = (size_t)lane * V;
-    const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + lane_off;
-    T *Qwt = static_cast<T *>(g.Qw) + (size_t)tile * (size_t)a.E * F + lane_off;
+    /* Q: wave-uniform row addresses plus a 32-bit lane offset (scalar base + vector offset addressing: the slots of a
+     * row are unrelated, one 64-bit vector address each would cost 2 registers per message in flight) */
+    const unsigned lane_q = (unsigned)lane * V;
+    const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F;
+    T *Qwt = static_cast<T *>(g.Qw) + (size_t)tile * (size_t)a.E * F;
     T *Rt = static_cast<T *>(a.R) + (size_t)tile * (size_t)a.E * F + lane_off;
     const T *chan_t = static_cast<const T *>(g.chan) + (size_t)tile * (size_t)g.N * F + lane_off;
     uint64_t *hard_t = g.hard + (size_t)tile * (size_t)g.N * V;
@@ -685,10 +721,13 @@ __global__ __launch_bounds__(kBlock) LDPC_LINK_WIDE_ATTR void check_link_kernel(
 
     /* software pipeline: row r+1's messages are requested before row r is worked on */
     float x[D][V];
-    if (r_begin < r_end) {
-        const int e0 = a.cls_e0[r_begin];
+    int qc[D], qn[D];                /* Q slots (CheckArgs::qpos) of this row's and of the next row's messages */
 #pragma unroll
-        for (int k = 0; k < D; ++k) vload<V>(x[k], Qt + (size_t)(e0 + k) * F);
+    for (int k = 0; k < D; ++k) qc[k] = qn[k] = 0;
+    if (r_begin < r_end) {
+        row_slots<D>(a.qpos, a.cls_e0[r_begin], lane, qc);
+#pragma unroll
+        for (int k = 0; k < D; ++k) vload<V>(x[k], Qt + (size_t)qc[k] * F + lane_q);
     }
     for (int r = r_begin; r < r_end; ++r) {
         const int e0 = a.cls_e0[r];
@@ -696,6 +735,8 @@ __global__ __launch_bounds__(kBlock) LDPC_LINK_WIDE_ATTR void check_link_kernel(
         const int pos = g.link_pos[r];
         const int ka = next_col >= 0 ? (pos & 255) : -1;      /* this row's edge into next_col */
         const int kb = pend_col >= 0 ? pend_kb : -1;          /* this row's edge into pend_col */
+        /* the next row's slots: asked for here, ahead of the row's arithmetic */
+        if (r + 1 < r_end) row_slots<D>(a.qpos, a.cls_e0[r + 1], lane, qn);
         /* everything the pending column needs besides this row's result: request it now */
         float ch[V];
         uint64_t old_w[V];
@@ -707,9 +748,8 @@ __global__ __launch_bounds__(kBlock) LDPC_LINK_WIDE_ATTR void check_link_kernel(
         float out[D][V];
         if (ALGO == kAlgoSP) check_sp<D, V>(x, out); else check_ms<D, V>(x, out);
         if (r + 1 < r_end) {
-            const int e1 = a.cls_e0[r + 1];
 #pragma unroll
-            for (int k = 0; k < D; ++k) vload<V>(x[k], Qt + (size_t)(e1 + k) * F);
+            for (int k = 0; k < D; ++k) vload<V>(x[k], Qt + (size_t)qn[k] * F + lane_q);
         }
 #pragma unroll
         for (int k = 0; k < D; ++k)
@@ -753,13 +793,18 @@ __global__ __launch_bounds__(kBlock) LDPC_LINK_WIDE_ATTR void check_link_kernel(
                     hard_t[(size_t)pend_col * V + v] = (old_w[v] & frozen[v]) | (new_w[v] & ~frozen[v]);
             }
             if (g.write_q) {
-                vstore<V>(Qwt + (size_t)pend_edge * F, q[0]);
-                vstore<V>(Qwt + (size_t)(e0 + kb) * F, q[1]);
+                int qw1 = qc[0];                              /* slot of this row's edge kb */
+#pragma unroll
+                for (int k = 1; k < D; ++k) qw1 = (k == kb) ? qc[k] : qw1;
+                vstore<V>(Qwt + (size_t)pend_edge * F + lane_q, q[0]);
+                vstore<V>(Qwt + (size_t)qw1 * F + lane_q, q[1]);
             }
         }
         pend_col = next_col;
         if (next_col >= 0) {
-            pend_edge = e0 + ka;
+            pend_edge = qc[0];                                /* SLOT of this row's edge ka: written by the next row */
+#pragma unroll
+            for (int k = 1; k < D; ++k) pend_edge = (k == ka) ? qc[k] : pend_edge;
             pend_kb = (pos >> 8) & 255;
 #pragma unroll
             for (int v = 0; v < V; ++v) {
@@ -769,6 +814,8 @@ __global__ __launch_bounds__(kBlock) LDPC_LINK_WIDE_ATTR void check_link_kernel(
                 pend_r[v] = t;
             }
         }
+#pragma unroll
+        for (int k = 0; k < D; ++k) qc[k] = qn[k];
     }
 }
 
@@ -817,8 +864,9 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow_kernel(const CheckAr
     int r_begin, r_end;
     link_chunk_rows(wave / SUBS, a.rows_per_wave, g.n_big, g.small_rows, a.n_rows, &r_begin, &r_end);
     const size_t lane_off = (size_t)sub * 64 * W + (size_t)lane * W;
-    const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F + lane_off;
-    T *Qwt = static_cast<T *>(g.Qw) + (size_t)tile * (size_t)a.E * F + lane_off;
+    const unsigned lane_q = (unsigned)lane_off;      /* Q: wave-uniform row addresses + 32-bit lane offset (check_link_kernel) */
+    const T *Qt = static_cast<const T *>(a.Q) + (size_t)tile * (size_t)a.E * F;
+    T *Qwt = static_cast<T *>(g.Qw) + (size_t)tile * (size_t)a.E * F;
     T *Rt = static_cast<T *>(a.R) + (size_t)tile * (size_t)a.E * F + lane_off;
     const T *chan_t = static_cast<const T *>(g.chan) + (size_t)tile * (size_t)g.N * F + lane_off;
     /* this lane's value w is frame 64*W*sub + W*lane + w of the tile = V*l' + v'
@@ -840,10 +888,13 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow_kernel(const CheckAr
 #pragma unroll
     for (int w = 0; w < W; ++w) pend_r[w] = 0.0f;
     float x[D][W];
-    if (r_begin < r_end) {
-        const int e0 = a.cls_e0[r_begin];
+    int qc[D], qn[D];                /* Q slots of this row's and of the next row's messages */
 #pragma unroll
-        for (int k = 0; k < D; ++k) vload<W>(x[k], Qt + (size_t)(e0 + k) * F);
+    for (int k = 0; k < D; ++k) qc[k] = qn[k] = 0;
+    if (r_begin < r_end) {
+        row_slots<D>(a.qpos, a.cls_e0[r_begin], lane, qc);
+#pragma unroll
+        for (int k = 0; k < D; ++k) vload<W>(x[k], Qt + (size_t)qc[k] * F + lane_q);
     }
     for (int r = r_begin; r < r_end; ++r) {
         const int e0 = a.cls_e0[r];
@@ -851,6 +902,7 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow_kernel(const CheckAr
         const int pos = g.link_pos[r];
         const int ka = next_col >= 0 ? (pos & 255) : -1;
         const int kb = pend_col >= 0 ? pend_kb : -1;
+        if (r + 1 < r_end) row_slots<D>(a.qpos, a.cls_e0[r + 1], lane, qn);
         float ch[W];
         uint64_t old_mine[W];
 #pragma unroll
@@ -863,9 +915,8 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow_kernel(const CheckAr
         float out[D][W];
         if (ALGO == kAlgoSP) check_sp<D, W>(x, out); else check_ms<D, W>(x, out);
         if (r + 1 < r_end) {
-            const int e1 = a.cls_e0[r + 1];
 #pragma unroll
-            for (int k = 0; k < D; ++k) vload<W>(x[k], Qt + (size_t)(e1 + k) * F);
+            for (int k = 0; k < D; ++k) vload<W>(x[k], Qt + (size_t)qn[k] * F + lane_q);
         }
 #pragma unroll
         for (int k = 0; k < D; ++k)
@@ -916,13 +967,18 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow_kernel(const CheckAr
                 else *reinterpret_cast<uint16_t *>(p) = (uint16_t)res;
             }
             if (g.write_q) {
-                vstore<W>(Qwt + (size_t)pend_edge * F, q[0]);
-                vstore<W>(Qwt + (size_t)(e0 + kb) * F, q[1]);
+                int qw1 = qc[0];
+#pragma unroll
+                for (int k = 1; k < D; ++k) qw1 = (k == kb) ? qc[k] : qw1;
+                vstore<W>(Qwt + (size_t)pend_edge * F + lane_q, q[0]);
+                vstore<W>(Qwt + (size_t)qw1 * F + lane_q, q[1]);
             }
         }
         pend_col = next_col;
         if (next_col >= 0) {
-            pend_edge = e0 + ka;
+            pend_edge = qc[0];                                /* SLOT of this row's edge ka */
+#pragma unroll
+            for (int k = 1; k < D; ++k) pend_edge = (k == ka) ? qc[k] : pend_edge;
             pend_kb = (pos >> 8) & 255;
 #pragma unroll
             for (int w = 0; w < W; ++w) {
@@ -932,6 +988,8 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow_kernel(const CheckAr
                 pend_r[w] = t;
             }
         }
+#pragma unroll
+        for (int k = 0; k < D; ++k) qc[k] = qn[k];
     }
 }
 
@@ -978,7 +1036,7 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow2_kernel(const CheckA
     auto load_row = [&](float (&dst)[D], int r) {
         const int e = a.cls_e0[r];
 #pragma unroll
-        for (int k = 0; k < D; ++k) { float t[1]; vload<1>(t, Qt + (size_t)(e + k) * F); dst[k] = t[0]; }
+        for (int k = 0; k < D; ++k) { float t[1]; vload<1>(t, Qt + (size_t)edge_slot(a.qpos, e + k) * F); dst[k] = t[0]; }
     };
     if (r_begin < r_end) load_row(b0, r_begin);
     if (r_begin + 1 < r_end) load_row(b1, r_begin + 1);
@@ -1035,8 +1093,8 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow2_kernel(const CheckA
                 else *reinterpret_cast<uint16_t *>(p) = (uint16_t)res;
             }
             if (g.write_q) {
-                vstore<1>(Qwt + (size_t)pend_edge * F, q[0]);
-                vstore<1>(Qwt + (size_t)(e0 + kb) * F, q[1]);
+                vstore<1>(Qwt + (size_t)edge_slot(a.qpos, pend_edge) * F, q[0]);
+                vstore<1>(Qwt + (size_t)edge_slot(a.qpos, e0 + kb) * F, q[1]);
             }
         }
         pend_col = next_col;
@@ -1065,7 +1123,7 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow2_kernel(const CheckA
 template <int ALGO, int D, int V, typename T>
 __device__ __forceinline__ void var_columns(const T *Rt, T *Qt, const T *chan_t, uint64_t *hard_t, const uint64_t (&frozen)[V],
                                             const int32_t *__restrict__ cls_col, const int32_t *__restrict__ cls_edge,
-                                            int c_begin, int c_end, int write_q, int lane)
+                                            int c_begin, int c_end, int write_q, int lane, int64_t q_base)
 {
     constexpr size_t F = 64 * V;
     for (int ci = c_begin; ci < c_end; ++ci) {
@@ -1109,8 +1167,14 @@ __device__ __forceinline__ void var_columns(const T *Rt, T *Qt, const T *chan_t,
                 hard_t[(size_t)n * V + v] = (old_w[v] & frozen[v]) | (new_w[v] & ~frozen[v]);
         }
         if (write_q) {
+            if (q_base >= 0) {
+                T *Qc = Qt + ((size_t)q_base + (size_t)ci * D) * F;        /* this column's run of D slots */
 #pragma unroll
-            for (int k = 0; k < D; ++k) vstore<V>(Qt + (size_t)e[k] * F, q[k]);
+                for (int k = 0; k < D; ++k) vstore<V>(Qc + (size_t)k * F, q[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < D; ++k) vstore<V>(Qt + (size_t)e[k] * F, q[k]);
+            }
         }
     }
 }
@@ -1139,24 +1203,24 @@ __global__ __launch_bounds__(kBlock) LDPC_VAR_ATTR void var_kernel(const VarArgs
     uint64_t frozen[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) frozen[v] = a.done[(size_t)tile * V + v];
-    var_columns<ALGO, D, V, T>(Rt, Qt, chan_t, hard_t, frozen, a.cls_col, a.cls_edge, c_begin, c_end, a.write_q, lane);
+    var_columns<ALGO, D, V, T>(Rt, Qt, chan_t, hard_t, frozen, a.cls_col, a.cls_edge, c_begin, c_end, a.write_q, lane, a.q_base);
 }
 
 template <int ALGO, int V, typename T, int D, int DLO> struct VarDispatch {
     static __device__ __forceinline__ void run(int deg, const T *Rt, T *Qt, const T *chan_t, uint64_t *hard_t,
                                                const uint64_t (&frozen)[V], const int32_t *col, const int32_t *edge,
-                                               int cb, int ce, int write_q, int lane)
+                                               int cb, int ce, int write_q, int lane, int64_t q_base)
     {
-        if (deg == D) var_columns<ALGO, D, V, T>(Rt, Qt, chan_t, hard_t, frozen, col, edge, cb, ce, write_q, lane);
-        else VarDispatch<ALGO, V, T, D - 1, DLO>::run(deg, Rt, Qt, chan_t, hard_t, frozen, col, edge, cb, ce, write_q, lane);
+        if (deg == D) var_columns<ALGO, D, V, T>(Rt, Qt, chan_t, hard_t, frozen, col, edge, cb, ce, write_q, lane, q_base);
+        else VarDispatch<ALGO, V, T, D - 1, DLO>::run(deg, Rt, Qt, chan_t, hard_t, frozen, col, edge, cb, ce, write_q, lane, q_base);
     }
 };
 template <int ALGO, int V, typename T, int DLO> struct VarDispatch<ALGO, V, T, DLO, DLO> {
     static __device__ __forceinline__ void run(int, const T *Rt, T *Qt, const T *chan_t, uint64_t *hard_t,
                                                const uint64_t (&frozen)[V], const int32_t *col, const int32_t *edge,
-                                               int cb, int ce, int write_q, int lane)
+                                               int cb, int ce, int write_q, int lane, int64_t q_base)
     {
-        var_columns<ALGO, DLO, V, T>(Rt, Qt, chan_t, hard_t, frozen, col, edge, cb, ce, write_q, lane);
+        var_columns<ALGO, DLO, V, T>(Rt, Qt, chan_t, hard_t, frozen, col, edge, cb, ce, write_q, lane, q_base);
     }
 };
 
@@ -1182,7 +1246,7 @@ __global__ __launch_bounds__(kBlock) void var_group_kernel(const VarArgs a, cons
 #pragma unroll
     for (int v = 0; v < V; ++v) frozen[v] = a.done[(size_t)tile * V + v];
     VarDispatch<ALGO, V, T, DHI, DLO>::run(cls[c].degree, Rt, Qt, chan_t, hard_t, frozen, cls[c].ids, cls[c].edges,
-                                           c_begin, c_end, a.write_q, lane);
+                                           c_begin, c_end, a.write_q, lane, cls[c].q_base);
 }
 
 template <int ALGO, int V, typename T>
@@ -1208,6 +1272,7 @@ __global__ __launch_bounds__(kBlock) void var_kernel_generic(const VarArgs a)
     for (int ci = c_begin; ci < c_end; ++ci) {
         const int n = a.cls_col[ci];
         const int32_t *e = a.cls_edge + (size_t)ci * D;
+        auto qs = [&](int k) -> size_t { return a.q_base >= 0 ? (size_t)a.q_base + (size_t)ci * D + k : (size_t)e[k]; };
         float ch[V];
         vload<V>(ch, chan_t + (size_t)n * F);
         uint64_t old_w[V], new_w[V];
@@ -1243,7 +1308,7 @@ __global__ __launch_bounds__(kBlock) void var_kernel_generic(const VarArgs a)
                             const float s = t0[v] + t1[v];
                             o[v] = t0[v] / s - t1[v] / s;
                         }
-                        vstore<V>(Qt + (size_t)e[k] * F, o);
+                        vstore<V>(Qt + qs(k) * F, o);
                     }
                 } else {
 #pragma unroll
@@ -1272,7 +1337,7 @@ __global__ __launch_bounds__(kBlock) void var_kernel_generic(const VarArgs a)
                     vload<V>(rj, Rt + (size_t)e[j] * F);
 #pragma unroll
                     for (int v = 0; v < V; ++v) o[v] = p[v] - rj[v];
-                    vstore<V>(Qt + (size_t)e[j] * F, o);
+                    vstore<V>(Qt + qs(j) * F, o);
                 }
             }
         }
@@ -1451,18 +1516,23 @@ __host__ __device__ inline size_t child_elem(int j, int cf, int64_t rows, int64_
  * per-column values of the running frames, gathered into the child's tiles.  One wave per row i and 64 slots. */
 template <int V, typename T>
 __global__ __launch_bounds__(kBlock) void compact_gather_kernel(const T *__restrict__ src, T *__restrict__ dst,
-                                                                const int32_t *__restrict__ map, int32_t count, int64_t rows, int cf)
+                                                                const int32_t *__restrict__ map, int32_t count, int64_t rows, int cf,
+                                                                const int32_t *__restrict__ src_row = nullptr,
+                                                                const int32_t *__restrict__ dst_row = nullptr)
 {
+    /* src_row / dst_row: where row i lives in the parent's / the child's array (the Q arrays: CheckArgs::qpos of either
+     * decoder -- their column-fused edges differ with the tile size); nullptr: row i */
     constexpr int F = 64 * V;
     const int j = threadIdx.x & 63, jg = blockIdx.y * 64 + j;               /* slot jg */
     const int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + wave_id_in_block();
     if (i >= rows) return;
+    const int64_t is = src_row ? src_row[i] : i, id = dst_row ? dst_row[i] : i;
     T val = (T)0;
     if (jg < count) {
         const int64_t f = map[jg];
-        val = src[((f / F) * rows + i) * F + (f % F)];
+        val = src[((f / F) * rows + is) * F + (f % F)];
     }
-    dst[child_elem(jg, cf, rows, i)] = val;
+    dst[child_elem(jg, cf, rows, id)] = val;
 }
 
 /* The same gather for MANY frames (hundreds, sitting in every tile of the batch): one thread per element as
@@ -1474,12 +1544,15 @@ constexpr int kGatherChunk = 4096;      /* elements staged at a time (16 KB of f
 template <int V, typename T>
 __global__ __launch_bounds__(kBlock) void compact_gather_rows_kernel(const T *__restrict__ src, T *__restrict__ dst,
                                                                      const int32_t *__restrict__ map, int32_t count,
-                                                                     int64_t rows, int32_t tiles, int cf)
+                                                                     int64_t rows, int32_t tiles, int cf,
+                                                                     const int32_t *__restrict__ src_row = nullptr,
+                                                                     const int32_t *__restrict__ dst_row = nullptr)
 {
     constexpr int F = 64 * V;
     constexpr int TPC = kGatherChunk / F;               /* parent tiles per chunk */
     __shared__ __attribute__((aligned(16))) T stage[kGatherChunk];
-    const int64_t i = blockIdx.x;
+    const int64_t i = src_row ? src_row[blockIdx.x] : blockIdx.x;       /* the row in the parent ... */
+    const int64_t id = dst_row ? dst_row[blockIdx.x] : blockIdx.x;      /* ... and in the child */
     const int cslots = ((count + cf - 1) / cf) * cf;    /* child slots in use (whole child tiles) */
     for (int t0 = 0; t0 < tiles; t0 += TPC) {
         const int nt = min(TPC, tiles - t0);
@@ -1492,9 +1565,9 @@ __global__ __launch_bounds__(kBlock) void compact_gather_rows_kernel(const T *__
         for (int j = threadIdx.x; j < cslots; j += kBlock) {
             if (j < count) {
                 const int f = map[j] - t0 * F;
-                if (f >= 0 && f < nt * F) dst[child_elem(j, cf, rows, i)] = stage[f];
+                if (f >= 0 && f < nt * F) dst[child_elem(j, cf, rows, id)] = stage[f];
             } else if (t0 == 0) {
-                dst[child_elem(j, cf, rows, i)] = (T)0;
+                dst[child_elem(j, cf, rows, id)] = (T)0;
             }
         }
         __syncthreads();

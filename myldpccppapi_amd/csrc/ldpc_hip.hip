@@ -155,6 +155,7 @@ struct ColClass {
     int degree = 0;
     int count = 0;
     DevBuf<int32_t> col, edge;
+    int64_t q_base = -1;     /* first Q slot of the class when Q is stored in writer order (VarArgs::q_base) */
 };
 
 /* the classes of one degree bucket that share a launch */
@@ -188,6 +189,9 @@ struct ldpc_decoder {
     std::vector<int32_t> h_col_ptr, h_col_edge, h_rows, h_cols;
 
     DevBuf<int32_t> row_ptr, edge_col, col_ptr, col_edge;
+    /* Q in writer order (CheckArgs::qpos): slot of every edge, and col_edge with slots in place of edge ids (init_kernel) */
+    DevBuf<int32_t> qpos, col_qedge;
+    std::vector<int32_t> h_qpos;
     DevBuf<uint8_t> chan, Q, R;         /* message arrays: msg_size bytes per element */
     int msg_size = 4;                   /* 4 = fp32, 2 = fp16 (LDPC_MSG_F16) */
     InitFn init_fn = nullptr;
@@ -456,6 +460,7 @@ template <int V> int enqueue_check_phase(ldpc_decoder *d, hipStream_t s, int til
                                   ((int64_t)rc.degree * rc.count - 2 * rc.linked) +
                                   (it < max_iter ? 2 * rc.linked : 0) + 2 * d->extra_edges) * frames));
         CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree, tr};
+        a.qpos = d->qpos.p;
         LinkArgs lk{rc.link_col.p, rc.link_pos.p, d->chan.p, d->Q.p, d->hard.p, d->N,
                     (it < max_iter) ? 1 : 0, d->tap_iter ? 1 : 0, d->extra_e0.p, d->extra_deg.p, d->n_extra, 0,
                     rc.n_big, rc.small_rows};
@@ -474,6 +479,7 @@ template <int V> int enqueue_check_phase(ldpc_decoder *d, hipStream_t s, int til
         for (int i : g.members) edges += (int64_t)d->row_classes[i].degree * d->row_classes[i].count;
         HIP_TRY(span_begin(d, s, 5, g.hi, 2 * msz * edges * frames, -1, g.lo));
         CheckArgs a{d->Q.p, d->R.p, nullptr, d->done.p, d->E, 0, (d->tune_rpw ? d->tune_rpw : 2) * (fat ? kIdleFat : 1), 0, tr};
+        a.qpos = d->qpos.p;
         if (it == 1 && d->first_round_from_chan) { a.first_chan = d->chan.p; a.edge_col = d->edge_col.p; a.N = d->N; }
         const dim3 grid = flood_grid(d, fat ? g.blocks_fat : g.blocks, tiles, &a.tiles_first);
         d->check_group_fn[g.bucket]<<<grid, kBlock, 0, s>>>(a, fat ? g.table_fat.p : g.table.p, (int)g.members.size());
@@ -483,6 +489,7 @@ template <int V> int enqueue_check_phase(ldpc_decoder *d, hipStream_t s, int til
         RowClass &rc = d->row_classes[ci];
         HIP_TRY(span_begin(d, s, 0, rc.degree, 2 * msz * rc.degree * rc.count * frames));
         CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, 1, rc.degree, tr};
+        a.qpos = d->qpos.p;
         if (it == 1 && d->first_round_from_chan) { a.first_chan = d->chan.p; a.edge_col = d->edge_col.p; a.N = d->N; }
         const int slotk = rc.degree <= d->max_check_unrolled ? rc.degree : 0;
         const bool narrow = slotk && (!d->tune_check_wide || rc.degree > kMaxUnrolledDegree);
@@ -521,6 +528,7 @@ template <int V> int enqueue_var_phase(ldpc_decoder *d, hipStream_t s, int tiles
                   d->E, d->N, cc.count, 1, wq, cc.degree, tr};
         const int cpw = (d->tune_cpw ? d->tune_cpw : 1) * (fat ? kIdleFat : 1);
         a.cols_per_wave = cpw;
+        a.q_base = cc.q_base;
         const int slotk = cc.degree <= kMaxUnrolledDegree ? cc.degree : 0;
         const int waves = (cc.count + cpw - 1) / cpw;
         const dim3 grid = flood_grid(d, (waves + kWavesPerBlock - 1) / kWavesPerBlock, tiles, &a.tiles_first);
@@ -553,18 +561,18 @@ template <int V> int compact_and_finish(ldpc_decoder *d, int64_t frames, int cou
     const int ptiles = (int)((frames + 64 * V - 1) / (64 * V));
     if (d->msg_size == 2) {
         if (rowwise) {
-            compact_gather_rows_kernel<V, _Float16><<<(unsigned)d->E, kBlock, 0, s>>>((const _Float16 *)d->Q.p, (_Float16 *)c->Q.p, d->cmap.p, count, d->E, ptiles, cf);
+            compact_gather_rows_kernel<V, _Float16><<<(unsigned)d->E, kBlock, 0, s>>>((const _Float16 *)d->Q.p, (_Float16 *)c->Q.p, d->cmap.p, count, d->E, ptiles, cf, d->qpos.p, c->qpos.p);
             compact_gather_rows_kernel<V, _Float16><<<(unsigned)d->N, kBlock, 0, s>>>((const _Float16 *)d->chan.p, (_Float16 *)c->chan.p, d->cmap.p, count, d->N, ptiles, cf);
         } else {
-            compact_gather_kernel<V, _Float16><<<ge, kBlock, 0, s>>>((const _Float16 *)d->Q.p, (_Float16 *)c->Q.p, d->cmap.p, count, d->E, cf);
+            compact_gather_kernel<V, _Float16><<<ge, kBlock, 0, s>>>((const _Float16 *)d->Q.p, (_Float16 *)c->Q.p, d->cmap.p, count, d->E, cf, d->qpos.p, c->qpos.p);
             compact_gather_kernel<V, _Float16><<<gn, kBlock, 0, s>>>((const _Float16 *)d->chan.p, (_Float16 *)c->chan.p, d->cmap.p, count, d->N, cf);
         }
     } else {
         if (rowwise) {
-            compact_gather_rows_kernel<V, float><<<(unsigned)d->E, kBlock, 0, s>>>((const float *)d->Q.p, (float *)c->Q.p, d->cmap.p, count, d->E, ptiles, cf);
+            compact_gather_rows_kernel<V, float><<<(unsigned)d->E, kBlock, 0, s>>>((const float *)d->Q.p, (float *)c->Q.p, d->cmap.p, count, d->E, ptiles, cf, d->qpos.p, c->qpos.p);
             compact_gather_rows_kernel<V, float><<<(unsigned)d->N, kBlock, 0, s>>>((const float *)d->chan.p, (float *)c->chan.p, d->cmap.p, count, d->N, ptiles, cf);
         } else {
-            compact_gather_kernel<V, float><<<ge, kBlock, 0, s>>>((const float *)d->Q.p, (float *)c->Q.p, d->cmap.p, count, d->E, cf);
+            compact_gather_kernel<V, float><<<ge, kBlock, 0, s>>>((const float *)d->Q.p, (float *)c->Q.p, d->cmap.p, count, d->E, cf, d->qpos.p, c->qpos.p);
             compact_gather_kernel<V, float><<<gn, kBlock, 0, s>>>((const float *)d->chan.p, (float *)c->chan.p, d->cmap.p, count, d->N, cf);
         }
     }
@@ -640,7 +648,7 @@ template <int V> int run_flooding(ldpc_decoder *d, const float *llr_dev, int64_t
     d->first_round_from_chan = q_less;
     if (!resume) {
         HIP_TRY(span_begin(d, s, 3));
-        InitArgs a{llr_dev, d->chan.p, q_less ? nullptr : d->Q.p, d->hard.p, d->col_ptr.p, d->col_edge.p,
+        InitArgs a{llr_dev, d->chan.p, q_less ? nullptr : d->Q.p, d->hard.p, d->col_ptr.p, d->col_qedge.p,
                    d->E, frames, d->N, d->cfg.llr_scale};
         dim3 grid((d->N + kInitCols - 1) / kInitCols, tiles);
         d->init_fn<<<grid, kBlock, 0, s>>>(a);
@@ -828,6 +836,26 @@ int build_classes(ldpc_decoder *d, const ldpc_graph *g)
         HIP_TRY(cc.col.upload(kv.second));
         HIP_TRY(cc.edge.upload(edges));
     }
+    {
+        /* Q in the order its writers produce it (CheckArgs::qpos): the column classes one after the other, each column's
+         * edges ascending -- what a variable-node wave writes is one contiguous run --, then the fused columns' edges,
+         * which the column-fused check kernel writes row by row, in row order */
+        d->h_qpos.assign((size_t)g->E, -1);
+        int64_t slot = 0;
+        if (d->tune.q_order >= 0)
+            for (ColClass &cc : d->col_classes) {
+                cc.q_base = slot;
+                for (int32_t n : cols_by_deg[cc.degree])
+                    for (int32_t p = g->col_ptr[n]; p < g->col_ptr[n + 1]; ++p) d->h_qpos[(size_t)g->col_edge[p]] = (int32_t)slot++;
+            }
+        /* (tune_q_order = -1: every edge in its own slot, as in R) */
+        for (int64_t e = 0; e < g->E; ++e)
+            if (d->h_qpos[(size_t)e] < 0) d->h_qpos[(size_t)e] = d->tune.q_order >= 0 ? (int32_t)slot++ : (int32_t)e;
+        std::vector<int32_t> cq((size_t)g->E);
+        for (int64_t p = 0; p < g->E; ++p) cq[(size_t)p] = d->h_qpos[(size_t)g->col_edge[(size_t)p]];
+        HIP_TRY(d->qpos.upload(d->h_qpos));
+        HIP_TRY(d->col_qedge.upload(cq));
+    }
     return LDPC_OK;
 }
 
@@ -884,10 +912,10 @@ int plan_launches(ldpc_decoder *d)
             GroupClass gc{};
             if (rows) {
                 const RowClass &rc = d->row_classes[i];
-                gc.degree = rc.degree; gc.count = rc.count; gc.ids = rc.e0.p; gc.edges = nullptr;
+                gc.degree = rc.degree; gc.count = rc.count; gc.ids = rc.e0.p; gc.edges = nullptr; gc.q_base = -1;
             } else {
                 const ColClass &cc = d->col_classes[i];
-                gc.degree = cc.degree; gc.count = cc.count; gc.ids = cc.col.p; gc.edges = cc.edge.p;
+                gc.degree = cc.degree; gc.count = cc.count; gc.ids = cc.col.p; gc.edges = cc.edge.p; gc.q_base = cc.q_base;
             }
             auto blocks_of = [&](int per_wave) {
                 const int waves = ((gc.count + per_wave - 1) / per_wave) * (rows ? V / d->check_group_width : 1);
@@ -968,6 +996,7 @@ template <int V> int calibrate_link(ldpc_decoder *d)
     for (int rep = 0; rep < 4 && err == hipSuccess; ++rep) {
         for (int nar = 0; nar < candidates && err == hipSuccess; ++nar) {
             CheckArgs a{d->Q.p, d->R.p, rc.e0.p, d->done.p, d->E, rc.count, d->link_rpw, rc.degree, TailRef{nullptr, 0, 0}};
+            a.qpos = d->qpos.p;
             LinkArgs lk{rc.link_col.p, rc.link_pos.p, d->chan.p, d->Q.p, d->hard.p, d->N, 1, 0, nullptr, nullptr, 0, 0,
                         rc.n_big, rc.small_rows};
             const int waves = link_chunk_count(d->link_rpw, rc.n_big, rc.small_rows, rc.count) * (nar == 1 ? V : nar == 2 ? V / 2 : 1);
@@ -2136,11 +2165,12 @@ int ldpc_decoder_dump(ldpc_decoder *d, int32_t which, float *host_out, int64_t c
                 const int64_t f = (int64_t)t * F + fi;
                 if (f >= frames) break;
                 for (int64_t i = 0; i < per; ++i) {
+                    const size_t ir = (which == 1 && !d->h_qpos.empty()) ? (size_t)d->h_qpos[(size_t)i] : (size_t)i;   /* Q: slot of edge i */
                     if (esz == 4) {
-                        memcpy(&host_out[f * per + i], &tile[((size_t)i * F + fi) * 4], 4);
+                        memcpy(&host_out[f * per + i], &tile[(ir * F + fi) * 4], 4);
                     } else {
                         _Float16 h;
-                        memcpy(&h, &tile[((size_t)i * F + fi) * 2], 2);
+                        memcpy(&h, &tile[(ir * F + fi) * 2], 2);
                         host_out[f * per + i] = (float)h;
                     }
                 }

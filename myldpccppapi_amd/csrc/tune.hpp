@@ -18,6 +18,7 @@ struct Tune {
     int compact = 0;            /* 0 automatic, -1 off */
     int ldsp_grid = 0, ldsp_per_cu = 0, ldsp_waves = 0;
     int place = 0;              /* array sets timed at creation: 0 automatic, 1 none, 2..8 */
+    int q_order = 0;            /* Q stored in the order its writers produce it: 0 automatic (on), 1 on, -1 off */
 };
 
 inline Tune tune_from_config(const ldpc_decoder_config &c)
@@ -47,6 +48,7 @@ inline Tune tune_from_config(const ldpc_decoder_config &c)
     t.ldsp_per_cu = c.tune_ldsp_shape & 255;
     t.ldsp_waves = (c.tune_ldsp_shape >> 8) & 255;
     t.place = c.tune_place;
+    t.q_order = c.tune_q_order;
     return t;
 }
 
@@ -64,7 +66,8 @@ inline bool tune_valid(const ldpc_decoder_config &c)
     return c.tune_rows_per_wave >= 0 && c.tune_rows_per_wave <= 4096 && c.tune_cols_per_wave >= 0 &&
            c.tune_cols_per_wave <= 4096 && c.tune_link_rows >= -1 && c.tune_link_rows <= 4096 &&
            c.tune_compact >= -1 && c.tune_ldsp_grid >= 0 && c.tune_ldsp_shape >= 0 && c.tune_ldsp_shape < 65536 &&
-           c.tune_place >= 0 && c.tune_place <= 8 && c.host_input >= 0 && c.host_input <= 2 && c.host_copy_threads >= 0 && c.host_copy_threads <= 16;
+           c.tune_place >= 0 && c.tune_place <= 8 && c.host_input >= 0 && c.host_input <= 2 && c.host_copy_threads >= 0 && c.host_copy_threads <= 16 &&
+           c.tune_q_order >= -1 && c.tune_q_order <= 1;
 }
 
 }  // namespace ldpc

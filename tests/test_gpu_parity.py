@@ -395,7 +395,10 @@ def test_column_local_fusion_on_staircase_code(built, algo):
                          # guided row chunks (the launch ends with chunks of a quarter of the rows), every kernel form
                          (16, {"link_guided": True}), (9, {"link_guided": True, "link_narrow": False}),
                          (16, {"link_guided": True, "link_half": True}), (12, {"link_guided": True, "link_deep": True}),
-                         (16, {"link_guided": True, "tiles_first": False}), (8, {"tiles_first": True})):
+                         (16, {"link_guided": True, "tiles_first": False}), (8, {"tiles_first": True}),
+                         # Q in edge order (as R) instead of the order its writers produce it, every kernel form; no fusion
+                         (16, {"q_order": -1}), (6, {"q_order": -1, "link_narrow": False}), (16, {"q_order": -1, "link_half": True}),
+                         (5, {"q_order": -1, "link_deep": True}), (-1, {"q_order": -1}), (16, {"q_order": 1, "merge": False})):
         for V in (1, 4):
             # link_deep: inputs requested two rows ahead; link_narrow False: V values per lane; link_half: 2 per lane (V = 4)
             dec = L.Decoder(g, K2, max_batch=70, algo=algo, max_iter=25, frames_per_lane=V,
@@ -660,10 +663,10 @@ def test_tail_compaction_of_running_frames(built, algo, f16):
     rows, cols = codes.wimax_edges(codes.RATE_1_2, 1152)
     n_conv = int(converged_frames(rows, cols, M, want["hard"]).sum())     # syndrome-clean, not iters < max
     assert n_conv >= int((want["iters"] < 30).sum())
-    for compact in (512, 7, -1):
+    for compact, q_order in ((512, 0), (7, 0), (-1, 0), (512, -1)):      # q_order -1: Q in edge order (parent and child)
         for fpl in (1, 2, 4):
             dec = L.Decoder(g, K, max_batch=B, algo=algo, max_iter=30, poll_interval=1, frames_per_lane=fpl,
-                            msg_dtype="f16" if f16 else "f32", tune={"compact": compact})
+                            msg_dtype="f16" if f16 else "f32", tune={"compact": compact, "q_order": q_order})
             for _ in range(2):                                    # the child is reused by the second call
                 out, iters = dec.decode(y)
                 assert np.array_equal(out, want["out"]), (compact, fpl)

@@ -124,7 +124,8 @@ def test_tuning_fields_are_validated_and_no_environment_is_read(built):
     lib = _lib.load()
     for field, value in (("tune_flags", 3), ("tune_flags", 1 << 30), ("tune_rows_per_wave", -1), ("tune_link_rows", -2),
                          ("tune_compact", -2), ("tune_ldsp_shape", 1 << 16), ("host_input", 3), ("host_input", -1),
-                         ("host_copy_threads", 17), ("host_copy_threads", -1)):
+                         ("host_copy_threads", 17), ("host_copy_threads", -1),
+                         ("tune_q_order", 2), ("tune_q_order", -2)):
         cfg = _lib.DecoderConfig()
         lib.ldpc_decoder_config_init(ctypes.byref(cfg))
         cfg.K, cfg.max_batch = 324, 4

@@ -30,7 +30,7 @@ typedef float vf4 __attribute__((ext_vector_type(4)));
 template <int D, int SEG4, bool NT>
 __global__ __launch_bounds__(256) void gather_kernel(const vf4 *__restrict__ src, vf4 *__restrict__ dst,
                                                      const vf4 *__restrict__ chan, const int32_t *__restrict__ idx,
-                                                     int n_cols)
+                                                     int n_cols, const int32_t *__restrict__ widx = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -38,6 +38,9 @@ __global__ __launch_bounds__(256) void gather_kernel(const vf4 *__restrict__ src
     int e[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) e[k] = __builtin_amdgcn_readfirstlane(idx[(size_t)col * D + k]);
+    int w[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) w[k] = widx ? __builtin_amdgcn_readfirstlane(widx[(size_t)col * D + k]) : e[k];
     vf4 r[D][SEG4], c[SEG4];
 #pragma unroll
     for (int s = 0; s < SEG4; ++s) c[s] = NT ? __builtin_nontemporal_load(&chan[((size_t)col * SEG4 + s) * 64 + lane])
@@ -60,8 +63,8 @@ __global__ __launch_bounds__(256) void gather_kernel(const vf4 *__restrict__ src
 #pragma unroll
         for (int s = 0; s < SEG4; ++s) {
             const vf4 q = sum[s] - r[k][s];
-            if (NT) __builtin_nontemporal_store(q, &dst[((size_t)e[k] * SEG4 + s) * 64 + lane]);
-            else dst[((size_t)e[k] * SEG4 + s) * 64 + lane] = q;
+            if (NT) __builtin_nontemporal_store(q, &dst[((size_t)w[k] * SEG4 + s) * 64 + lane]);
+            else dst[((size_t)w[k] * SEG4 + s) * 64 + lane] = q;
         }
 }
 
@@ -135,10 +138,20 @@ template <int D, int SEG4, bool NT> static void run(const char *name, vf4 *src, 
         for (int c = 0; c < groups * 360; ++c)
             for (int k = 0; k < D; ++k) perm[(size_t)c * D + k] = base[(size_t)(c / 360) * D + k] * 360 + c % 360;
     }
-    int32_t *idx;
+    /* streams = 3: random reads, writes in D contiguous streams; 4: reads in D contiguous streams, random writes
+     * (which of the two random sides costs: a layout can move all the randomness to the reads or to the writes) */
+    std::vector<int32_t> lin((size_t)n_cols * D);
+    for (int c = 0; c < n_cols; ++c)
+        for (int k = 0; k < D; ++k) lin[(size_t)c * D + k] = (int32_t)((size_t)k * n_cols + c);
+    int32_t *idx, *widx = nullptr;
     CHECK(hipMalloc((void **)&idx, (size_t)n_cols * D * sizeof(int32_t)));
-    CHECK(hipMemcpy(idx, perm.data(), (size_t)n_cols * D * sizeof(int32_t), hipMemcpyHostToDevice));
-    const float ms = time_ms([&] { gather_kernel<D, SEG4, NT><<<(n_cols + 3) / 4, 256>>>(src, dst, chan, idx, n_cols); }, 5);
+    CHECK(hipMemcpy(idx, streams == 4 ? lin.data() : perm.data(), (size_t)n_cols * D * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (streams >= 3) {
+        CHECK(hipMalloc((void **)&widx, (size_t)n_cols * D * sizeof(int32_t)));
+        CHECK(hipMemcpy(widx, streams == 3 ? lin.data() : perm.data(), (size_t)n_cols * D * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    const float ms = time_ms([&] { gather_kernel<D, SEG4, NT><<<(n_cols + 3) / 4, 256>>>(src, dst, chan, idx, n_cols, widx); }, 5);
+    if (widx) CHECK(hipFree(widx));
     const double bytes = (double)n_cols * (2.0 * D + 1.0) * seg_bytes;
     printf("%-44s %8.3f ms  %7.1f GB/s\n", name, ms, bytes / (ms * 1e-3) / 1e9);
     CHECK(hipFree(idx));
@@ -170,6 +183,12 @@ int main()
     run<8, 1, true>("D=8 contiguous streams, nt", src, dst, chan, total, 1);
     run<8, 1, false>("D=8 contiguous streams, default policy", src, dst, chan, total, 1);
     run<3, 1, true>("D=3 contiguous streams, nt", src, dst, chan, total, 1);
+    run<8, 1, true>("D=8 random reads, streamed writes, nt", src, dst, chan, total, 3);
+    run<8, 1, false>("D=8 random reads, streamed writes, default", src, dst, chan, total, 3);
+    run<8, 1, true>("D=8 streamed reads, random writes, nt", src, dst, chan, total, 4);
+    run<8, 1, false>("D=8 streamed reads, random writes, default", src, dst, chan, total, 4);
+    run<3, 1, true>("D=3 random reads, streamed writes, nt", src, dst, chan, total, 3);
+    run<3, 1, true>("D=3 streamed reads, random writes, nt", src, dst, chan, total, 4);
     run<8, 1, true>("D=8 runs of 360 segments, nt", src, dst, chan, total, 2);
     run<8, 1, false>("D=8 runs of 360 segments, default policy", src, dst, chan, total, 2);
     run<3, 1, true>("D=3 runs of 360 segments, nt", src, dst, chan, total, 2);
