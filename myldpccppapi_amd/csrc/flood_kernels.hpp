@@ -415,7 +415,7 @@ struct GroupClass {
     int32_t pad;
     const int32_t *ids;         /* rows: first edge ids; columns: column ids */
     const int32_t *edges;       /* columns: [count][degree] edge ids */
-    int64_t q_base;             /* columns: first Q slot of the class (VarArgs::q_base), -1: slot = edge id */
+    int64_t q_base;             /* columns: first Q slot of the class's D streams (VarArgs::q_base), -1: slot = edge id */
 };
 
 template <int ALGO, int D, int V, int W, typename T>
@@ -578,8 +578,10 @@ struct VarArgs {
     int32_t degree;                       /* generic kernel only */
     TailRef tail;
     int32_t tiles_first = 0;              /* grid is (tiles, blocks): grid_pos() */
-    /* first Q slot of this class (CheckArgs::qpos: Q is stored in the order its writers produce it): column ci of
-     * the class writes its D messages to slots q_base + ci * D ... -- one contiguous run per wave.  -1: slot = edge id. */
+    /* first Q slot of this class (CheckArgs::qpos: Q is stored in the order its writers produce it): the class owns D
+     * streams of n_cols slots, column ci writes message k to slot q_base + k * n_cols + ci -- the waves at work at any
+     * moment write D moving fronts (tools/gather_probe.hip: 6079 GB/s, against 5540 with one 8-KiB run per column and
+     * 5065 with the messages scattered to their edge ids).  -1: slot = edge id. */
     int64_t q_base = -1;
 };
 
@@ -1123,7 +1125,7 @@ __global__ __launch_bounds__(kBlock) void check_link_narrow2_kernel(const CheckA
 template <int ALGO, int D, int V, typename T>
 __device__ __forceinline__ void var_columns(const T *Rt, T *Qt, const T *chan_t, uint64_t *hard_t, const uint64_t (&frozen)[V],
                                             const int32_t *__restrict__ cls_col, const int32_t *__restrict__ cls_edge,
-                                            int c_begin, int c_end, int write_q, int lane, int64_t q_base)
+                                            int c_begin, int c_end, int write_q, int lane, int64_t q_base, int n_cls)
 {
     constexpr size_t F = 64 * V;
     for (int ci = c_begin; ci < c_end; ++ci) {
@@ -1168,9 +1170,9 @@ __device__ __forceinline__ void var_columns(const T *Rt, T *Qt, const T *chan_t,
         }
         if (write_q) {
             if (q_base >= 0) {
-                T *Qc = Qt + ((size_t)q_base + (size_t)ci * D) * F;        /* this column's run of D slots */
+                T *Qc = Qt + ((size_t)q_base + (size_t)ci) * F;            /* this column's slot in stream 0 */
 #pragma unroll
-                for (int k = 0; k < D; ++k) vstore<V>(Qc + (size_t)k * F, q[k]);
+                for (int k = 0; k < D; ++k) vstore<V>(Qc + (size_t)k * (size_t)n_cls * F, q[k]);
             } else {
 #pragma unroll
                 for (int k = 0; k < D; ++k) vstore<V>(Qt + (size_t)e[k] * F, q[k]);
@@ -1203,24 +1205,24 @@ __global__ __launch_bounds__(kBlock) LDPC_VAR_ATTR void var_kernel(const VarArgs
     uint64_t frozen[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) frozen[v] = a.done[(size_t)tile * V + v];
-    var_columns<ALGO, D, V, T>(Rt, Qt, chan_t, hard_t, frozen, a.cls_col, a.cls_edge, c_begin, c_end, a.write_q, lane, a.q_base);
+    var_columns<ALGO, D, V, T>(Rt, Qt, chan_t, hard_t, frozen, a.cls_col, a.cls_edge, c_begin, c_end, a.write_q, lane, a.q_base, a.n_cols);
 }
 
 template <int ALGO, int V, typename T, int D, int DLO> struct VarDispatch {
     static __device__ __forceinline__ void run(int deg, const T *Rt, T *Qt, const T *chan_t, uint64_t *hard_t,
                                                const uint64_t (&frozen)[V], const int32_t *col, const int32_t *edge,
-                                               int cb, int ce, int write_q, int lane, int64_t q_base)
+                                               int cb, int ce, int write_q, int lane, int64_t q_base, int n_cls)
     {
-        if (deg == D) var_columns<ALGO, D, V, T>(Rt, Qt, chan_t, hard_t, frozen, col, edge, cb, ce, write_q, lane, q_base);
-        else VarDispatch<ALGO, V, T, D - 1, DLO>::run(deg, Rt, Qt, chan_t, hard_t, frozen, col, edge, cb, ce, write_q, lane, q_base);
+        if (deg == D) var_columns<ALGO, D, V, T>(Rt, Qt, chan_t, hard_t, frozen, col, edge, cb, ce, write_q, lane, q_base, n_cls);
+        else VarDispatch<ALGO, V, T, D - 1, DLO>::run(deg, Rt, Qt, chan_t, hard_t, frozen, col, edge, cb, ce, write_q, lane, q_base, n_cls);
     }
 };
 template <int ALGO, int V, typename T, int DLO> struct VarDispatch<ALGO, V, T, DLO, DLO> {
     static __device__ __forceinline__ void run(int, const T *Rt, T *Qt, const T *chan_t, uint64_t *hard_t,
                                                const uint64_t (&frozen)[V], const int32_t *col, const int32_t *edge,
-                                               int cb, int ce, int write_q, int lane, int64_t q_base)
+                                               int cb, int ce, int write_q, int lane, int64_t q_base, int n_cls)
     {
-        var_columns<ALGO, DLO, V, T>(Rt, Qt, chan_t, hard_t, frozen, col, edge, cb, ce, write_q, lane, q_base);
+        var_columns<ALGO, DLO, V, T>(Rt, Qt, chan_t, hard_t, frozen, col, edge, cb, ce, write_q, lane, q_base, n_cls);
     }
 };
 
@@ -1246,7 +1248,7 @@ __global__ __launch_bounds__(kBlock) void var_group_kernel(const VarArgs a, cons
 #pragma unroll
     for (int v = 0; v < V; ++v) frozen[v] = a.done[(size_t)tile * V + v];
     VarDispatch<ALGO, V, T, DHI, DLO>::run(cls[c].degree, Rt, Qt, chan_t, hard_t, frozen, cls[c].ids, cls[c].edges,
-                                           c_begin, c_end, a.write_q, lane, cls[c].q_base);
+                                           c_begin, c_end, a.write_q, lane, cls[c].q_base, cls[c].count);
 }
 
 template <int ALGO, int V, typename T>
@@ -1272,7 +1274,7 @@ __global__ __launch_bounds__(kBlock) void var_kernel_generic(const VarArgs a)
     for (int ci = c_begin; ci < c_end; ++ci) {
         const int n = a.cls_col[ci];
         const int32_t *e = a.cls_edge + (size_t)ci * D;
-        auto qs = [&](int k) -> size_t { return a.q_base >= 0 ? (size_t)a.q_base + (size_t)ci * D + k : (size_t)e[k]; };
+        auto qs = [&](int k) -> size_t { return a.q_base >= 0 ? (size_t)a.q_base + (size_t)k * a.n_cols + ci : (size_t)e[k]; };
         float ch[V];
         vload<V>(ch, chan_t + (size_t)n * F);
         uint64_t old_w[V], new_w[V];

@@ -837,16 +837,19 @@ int build_classes(ldpc_decoder *d, const ldpc_graph *g)
         HIP_TRY(cc.edge.upload(edges));
     }
     {
-        /* Q in the order its writers produce it (CheckArgs::qpos): the column classes one after the other, each column's
-         * edges ascending -- what a variable-node wave writes is one contiguous run --, then the fused columns' edges,
-         * which the column-fused check kernel writes row by row, in row order */
+        /* Q in the order its writers produce it (CheckArgs::qpos): the column classes one after the other, a class of degree D
+         * as D streams of its columns' k-th messages -- the variable-node waves at work write D moving fronts --, then the
+         * fused columns' edges, which the column-fused check kernel writes row by row, in row order */
         d->h_qpos.assign((size_t)g->E, -1);
         int64_t slot = 0;
         if (d->tune.q_order >= 0)
             for (ColClass &cc : d->col_classes) {
                 cc.q_base = slot;
-                for (int32_t n : cols_by_deg[cc.degree])
-                    for (int32_t p = g->col_ptr[n]; p < g->col_ptr[n + 1]; ++p) d->h_qpos[(size_t)g->col_edge[p]] = (int32_t)slot++;
+                const std::vector<int32_t> &members = cols_by_deg[cc.degree];
+                for (size_t ci = 0; ci < members.size(); ++ci)
+                    for (int k = 0; k < cc.degree; ++k)
+                        d->h_qpos[(size_t)g->col_edge[(size_t)g->col_ptr[members[ci]] + k]] = (int32_t)(slot + (int64_t)k * cc.count + (int64_t)ci);
+                slot += (int64_t)cc.degree * cc.count;
             }
         /* (tune_q_order = -1: every edge in its own slot, as in R) */
         for (int64_t e = 0; e < g->E; ++e)

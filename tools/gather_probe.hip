@@ -146,9 +146,11 @@ template <int D, int SEG4, bool NT> static void run(const char *name, vf4 *src, 
     int32_t *idx, *widx = nullptr;
     CHECK(hipMalloc((void **)&idx, (size_t)n_cols * D * sizeof(int32_t)));
     CHECK(hipMemcpy(idx, streams == 4 ? lin.data() : perm.data(), (size_t)n_cols * D * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (streams == 5)      /* random reads, each column's D messages written as ONE run (the product's Q layout) */
+        for (size_t i = 0; i < lin.size(); ++i) lin[i] = (int32_t)i;
     if (streams >= 3) {
         CHECK(hipMalloc((void **)&widx, (size_t)n_cols * D * sizeof(int32_t)));
-        CHECK(hipMemcpy(widx, streams == 3 ? lin.data() : perm.data(), (size_t)n_cols * D * sizeof(int32_t), hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(widx, streams != 4 ? lin.data() : perm.data(), (size_t)n_cols * D * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     const float ms = time_ms([&] { gather_kernel<D, SEG4, NT><<<(n_cols + 3) / 4, 256>>>(src, dst, chan, idx, n_cols, widx); }, 5);
     if (widx) CHECK(hipFree(widx));
@@ -189,6 +191,8 @@ int main()
     run<8, 1, false>("D=8 streamed reads, random writes, default", src, dst, chan, total, 4);
     run<3, 1, true>("D=3 random reads, streamed writes, nt", src, dst, chan, total, 3);
     run<3, 1, true>("D=3 streamed reads, random writes, nt", src, dst, chan, total, 4);
+    run<8, 1, true>("D=8 random reads, one write run per column, nt", src, dst, chan, total, 5);
+    run<3, 1, true>("D=3 random reads, one write run per column, nt", src, dst, chan, total, 5);
     run<8, 1, true>("D=8 runs of 360 segments, nt", src, dst, chan, total, 2);
     run<8, 1, false>("D=8 runs of 360 segments, default policy", src, dst, chan, total, 2);
     run<3, 1, true>("D=3 runs of 360 segments, nt", src, dst, chan, total, 2);
