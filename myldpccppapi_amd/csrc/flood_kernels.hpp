@@ -1430,9 +1430,18 @@ __global__ __launch_bounds__(kBlock) void init_kernel(const InitArgs a)
             }
         }
         vstore<V>(static_cast<T *>(a.chan) + ((size_t)tile * a.N + n) * F + (size_t)lane * V, ch);
-        if (a.Q)        /* nullptr: round 1's check kernels read the channel values themselves (CheckArgs::first_chan) */
-            for (int p = a.col_ptr[n]; p < a.col_ptr[n + 1]; ++p)
-                vstore<V>(static_cast<T *>(a.Q) + ((size_t)tile * (size_t)a.E + (size_t)a.col_edge[p]) * F + (size_t)lane * V, q);
+        if (a.Q) {      /* nullptr: round 1's check kernels read the channel values themselves (CheckArgs::first_chan) */
+            /* the column's Q slots: one load by the wave's first lanes, a broadcast per store (a load per store
+             * serialised the stores behind the index latency) */
+            const int p0 = a.col_ptr[n], deg = a.col_ptr[n + 1] - p0;
+            T *Qt = static_cast<T *>(a.Q) + (size_t)tile * (size_t)a.E * F + (size_t)lane * V;
+            for (int k0 = 0; k0 < deg; k0 += 64) {
+                const int m = min(64, deg - k0);
+                const int mine = a.col_edge[p0 + k0 + (lane < m ? lane : m - 1)];
+                for (int k = 0; k < m; ++k)
+                    vstore<V>(Qt + (size_t)__builtin_amdgcn_readlane(mine, k) * F, q);
+            }
+        }
         if (lane < V) a.hard[((size_t)tile * a.N + n) * V + lane] = 0;
     }
 }
