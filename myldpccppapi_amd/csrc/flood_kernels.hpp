@@ -1552,6 +1552,7 @@ __global__ __launch_bounds__(kBlock) void compact_gather_kernel(const T *__restr
  * tiles into LDS with coalesced 16-byte loads, chunk by chunk, and picks the running frames' values from
  * there.  HBM traffic = one pass over the parent array (a third of a round) however many frames move. */
 constexpr int kGatherChunk = 4096;      /* elements staged at a time (16 KB of fp32) */
+constexpr int kGatherRowsPerBlock = 8;  /* rows a block walks */
 template <int V, typename T>
 __global__ __launch_bounds__(kBlock) void compact_gather_rows_kernel(const T *__restrict__ src, T *__restrict__ dst,
                                                                      const int32_t *__restrict__ map, int32_t count,
@@ -1561,27 +1562,60 @@ __global__ __launch_bounds__(kBlock) void compact_gather_rows_kernel(const T *__
 {
     constexpr int F = 64 * V;
     constexpr int TPC = kGatherChunk / F;               /* parent tiles per chunk */
+    constexpr int VEC = 16 / (int)sizeof(T);            /* 16 bytes per lane (a tile's row segment is F * sizeof(T) >= 128 bytes, 16-byte aligned) */
+    constexpr int NV = kGatherChunk / (kBlock * VEC);   /* 16-byte vectors a thread stages per chunk */
     __shared__ __attribute__((aligned(16))) T stage[kGatherChunk];
-    const int64_t i = src_row ? src_row[blockIdx.x] : blockIdx.x;       /* the row in the parent ... */
-    const int64_t id = dst_row ? dst_row[blockIdx.x] : blockIdx.x;      /* ... and in the child */
     const int cslots = ((count + cf - 1) / cf) * cf;    /* child slots in use (whole child tiles) */
-    for (int t0 = 0; t0 < tiles; t0 += TPC) {
-        const int nt = min(TPC, tiles - t0);
-        /* 16 bytes per lane (a tile's row segment is F * sizeof(T) >= 128 bytes, 16-byte aligned) */
-        constexpr int VEC = 16 / (int)sizeof(T);
-        for (int k = threadIdx.x * VEC; k < nt * F; k += kBlock * VEC)
-            *reinterpret_cast<vf4 *>(&stage[k]) =
-                ld_stream(reinterpret_cast<const vf4 *>(src + ((size_t)(t0 + k / F) * rows + i) * F + (k % F)));
-        __syncthreads();
-        for (int j = threadIdx.x; j < cslots; j += kBlock) {
-            if (j < count) {
-                const int f = map[j] - t0 * F;
-                if (f >= 0 && f < nt * F) dst[child_elem(j, cf, rows, id)] = stage[f];
-            } else if (t0 == 0) {
-                dst[child_elem(j, cf, rows, id)] = (T)0;
+    const int64_t r0 = (int64_t)blockIdx.x * kGatherRowsPerBlock;
+    const int64_t r1 = r0 + kGatherRowsPerBlock < rows ? r0 + kGatherRowsPerBlock : rows;
+    if (tiles <= TPC) {
+        /* the usual case, a row's segments of all tiles fit one chunk: the block walks its rows with the NEXT row's
+         * loads in flight while this row's values are picked from LDS (one row per block left the memory pipe idle
+         * during the pick: 3.6 TB/s on fp16 rows of 8 KB) */
+        vf4 pre[NV];
+        auto issue = [&](int64_t r) {
+            const int64_t i = src_row ? src_row[r] : r;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int k = (v * kBlock + (int)threadIdx.x) * VEC;
+                if (k < tiles * F) pre[v] = ld_stream(reinterpret_cast<const vf4 *>(src + ((size_t)(k / F) * rows + i) * F + (k % F)));
             }
+        };
+        if (r0 < r1) issue(r0);
+        for (int64_t r = r0; r < r1; ++r) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int k = (v * kBlock + (int)threadIdx.x) * VEC;
+                if (k < tiles * F) *reinterpret_cast<vf4 *>(&stage[k]) = pre[v];
+            }
+            __syncthreads();
+            if (r + 1 < r1) issue(r + 1);
+            const int64_t id = dst_row ? dst_row[r] : r;
+            for (int j = threadIdx.x; j < cslots; j += kBlock)
+                dst[child_elem(j, cf, rows, id)] = j < count ? stage[map[j]] : (T)0;
+            __syncthreads();
         }
-        __syncthreads();
+        return;
+    }
+    for (int64_t r = r0; r < r1; ++r) {
+        const int64_t i = src_row ? src_row[r] : r;         /* the row in the parent ... */
+        const int64_t id = dst_row ? dst_row[r] : r;        /* ... and in the child */
+        for (int t0 = 0; t0 < tiles; t0 += TPC) {
+            const int nt = min(TPC, tiles - t0);
+            for (int k = threadIdx.x * VEC; k < nt * F; k += kBlock * VEC)
+                *reinterpret_cast<vf4 *>(&stage[k]) =
+                    ld_stream(reinterpret_cast<const vf4 *>(src + ((size_t)(t0 + k / F) * rows + i) * F + (k % F)));
+            __syncthreads();
+            for (int j = threadIdx.x; j < cslots; j += kBlock) {
+                if (j < count) {
+                    const int f = map[j] - t0 * F;
+                    if (f >= 0 && f < nt * F) dst[child_elem(j, cf, rows, id)] = stage[f];
+                } else if (t0 == 0) {
+                    dst[child_elem(j, cf, rows, id)] = (T)0;
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
