@@ -1661,26 +1661,41 @@ template <int V> __global__ __launch_bounds__(kBlock) void compact_hard_kernel(u
  * frames that were handed over, the child's bit: inv[frame] = child slot, moved[(tile, v)] = which bits of
  * that word moved (both filled by compact_inverse_kernel). */
 template <int V> __global__ void compact_inverse_kernel(const int32_t *__restrict__ map, int32_t count, int32_t *__restrict__ inv,
-                                                        unsigned long long *__restrict__ moved)
+                                                        unsigned long long *__restrict__ moved, int cv)
 {
+    /* inv[f] = where slot j's bit sits in the child, decoded once here: (child word of the column) << 8 | bit
+     * (compact_hard_back_kernel did the four run-time divisions per moved frame and column: 79 us of integer arithmetic) */
     constexpr int F = 64 * V;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     const int f = map[j], fi = f % F;
-    inv[f] = j;
+    const int cf = 64 * cv, cfi = j % cf;
+    inv[f] = (((j / cf) * cv + cfi % cv) << 8) | (cfi / cv);
     atomicOr(&moved[(size_t)(f / F) * V + fi % V], 1ull << (fi / V));
 }
 
+constexpr int kBackWords = 16;          /* child mask words per column a block keeps: 1024 frames */
 template <int V> __global__ __launch_bounds__(kBlock) void compact_hard_back_kernel(uint64_t *__restrict__ parent, const uint64_t *__restrict__ child,
                                                                                     const int32_t *__restrict__ inv,
                                                                                     const unsigned long long *__restrict__ moved, int32_t N,
-                                                                                    int cv)
+                                                                                    int cv, int cwords)
 {
+    /* cwords = child tiles in use x cv <= kBackWords: the column's child words go to LDS once (thread-private
+     * entries, read back by a run-time index) -- one load per moved frame instead read 8 of every 32 fetched bytes,
+     * 1.4 GB through the L2 for 681 frames: 79 us */
     constexpr int F = 64 * V;
-    const int cf = 64 * cv;
+    __shared__ uint64_t cw[kBackWords][kBlock];
+    __shared__ int32_t sinv[F];             /* the tile's slots: a global load per moved frame put its latency into every trip */
     const int n = blockIdx.x * kBlock + threadIdx.x;
     const int tile = blockIdx.y;
+    bool any = false;
+#pragma unroll
+    for (int v = 0; v < V; ++v) any = any || moved[(size_t)tile * V + v] != 0;
+    if (!any) return;                       /* block-uniform */
+    for (int k = threadIdx.x; k < F; k += kBlock) sinv[k] = inv[tile * F + k];
+    __syncthreads();
     if (n >= N) return;
+    for (int w = 0; w < cwords; ++w) cw[w][threadIdx.x] = child[((size_t)(w / cv) * N + n) * cv + w % cv];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         uint64_t m = moved[(size_t)tile * V + v];
@@ -1689,9 +1704,8 @@ template <int V> __global__ __launch_bounds__(kBlock) void compact_hard_back_ker
         while (m) {
             const int l = __ffsll((unsigned long long)m) - 1;
             m &= m - 1;
-            const int j = inv[tile * F + l * V + v];
-            const int cfi = j % cf;
-            const uint64_t bit = (child[((size_t)(j / cf) * N + n) * cv + cfi % cv] >> (cfi / cv)) & 1ull;
+            const int j = sinv[l * V + v];                  /* child word << 8 | bit (compact_inverse_kernel) */
+            const uint64_t bit = (cw[j >> 8][threadIdx.x] >> (j & 255)) & 1ull;
             w = (w & ~(1ull << l)) | (bit << l);
         }
         parent[((size_t)tile * N + n) * V + v] = w;

@@ -272,7 +272,7 @@ struct ldpc_decoder {
      * frames of a polled, early-terminating decode */
     ldpc_decoder *child = nullptr;
     DevBuf<int32_t> cmap;               /* [child_capacity] frame indices handed to the child */
-    DevBuf<int32_t> cinv;               /* [max_batch] child slot of a handed-over frame (valid where cmoved says so) */
+    DevBuf<int32_t> cinv;               /* [max_batch] where a handed-over frame's bit sits in the child (valid where cmoved says so) */
     DevBuf<unsigned long long> cmoved;  /* [T][V] bits of each mask word whose frames were handed over */
     int child_capacity = ldpc::kCompactCapacity;      /* frames the child holds: 512, or 1024 for batches of >= 4096 frames */
     int compact_threshold = ldpc::kCompactCapacity;   /* cfg.tune_compact: 0 = off, else hand over when <= this many frames run */
@@ -551,6 +551,7 @@ template <int V> int compact_and_finish(ldpc_decoder *d, int64_t frames, int cou
     const int cv = c->V, cf = 64 * cv;                      /* its frames per lane and per tile */
     const unsigned ct = (unsigned)((count + cf - 1) / cf);  /* child tiles in use */
     const unsigned cg = ct * (unsigned)cv;                  /* ... in groups of 64 slots */
+    if (cg > (unsigned)kBackWords) return fail(LDPC_ERR_STATE, "hand-over of %d frames: more than %d mask words per column", count, kBackWords);
     HIP_TRY(hipMemsetAsync(d->active.p, 0, sizeof(int32_t), s));
     compact_list_kernel<V><<<(unsigned)((frames + kBlock - 1) / kBlock), kBlock, 0, s>>>(d->done.p, frames, d->cmap.p,
                                                                                          d->active.p, d->child_capacity);
@@ -592,9 +593,9 @@ template <int V> int compact_and_finish(ldpc_decoder *d, int64_t frames, int cou
     /* the bits back: every parent word collects its moved frames' bits (no atomics; the per-bit atomic scatter of
      * compact_hard_kernel took 53-80 us for a few dozen frames, this takes 10-30) */
     HIP_TRY(hipMemsetAsync(d->cmoved.p, 0, d->cmoved.n * sizeof(unsigned long long), s));
-    compact_inverse_kernel<V><<<(unsigned)((count + 255) / 256), 256, 0, s>>>(d->cmap.p, count, d->cinv.p, d->cmoved.p);
+    compact_inverse_kernel<V><<<(unsigned)((count + 255) / 256), 256, 0, s>>>(d->cmap.p, count, d->cinv.p, d->cmoved.p, cv);
     compact_hard_back_kernel<V><<<dim3((unsigned)((d->N + kBlock - 1) / kBlock), (unsigned)ptiles), kBlock, 0, s>>>(
-        d->hard.p, c->hard.p, d->cinv.p, d->cmoved.p, d->N, cv);
+        d->hard.p, c->hard.p, d->cinv.p, d->cmoved.p, d->N, cv, (int)cg);
     compact_finish_kernel<V><<<(unsigned)((count + 63) / 64), 64, 0, s>>>(d->done.p, d->iters.p, c->done.p, c->iters.p, d->cmap.p, count, cv);
     HIP_TRY(hipGetLastError());
     return LDPC_OK;
