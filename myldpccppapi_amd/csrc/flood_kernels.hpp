@@ -1582,6 +1582,17 @@ __global__ __launch_bounds__(kBlock) void compact_gather_rows_kernel(const T *__
             }
         };
         if (r0 < r1) issue(r0);
+        /* this thread's slots j = threadIdx.x + u * kBlock: where they come from and where they go is the same for every
+         * row (child_elem's run-time divisions, per element, were a quarter of a millisecond of integer arithmetic) */
+        constexpr int NS = (2 * kCompactCapacity + kBlock - 1) / kBlock;      /* slots per thread: 1024 frames at most */
+        int from[NS];
+        size_t to[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int j = (int)threadIdx.x + u * kBlock;
+            from[u] = j < count ? map[j] : -1;
+            to[u] = j < cslots ? child_elem(j, cf, rows, 0) : 0;
+        }
         for (int64_t r = r0; r < r1; ++r) {
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
@@ -1591,8 +1602,10 @@ __global__ __launch_bounds__(kBlock) void compact_gather_rows_kernel(const T *__
             __syncthreads();
             if (r + 1 < r1) issue(r + 1);
             const int64_t id = dst_row ? dst_row[r] : r;
-            for (int j = threadIdx.x; j < cslots; j += kBlock)
-                dst[child_elem(j, cf, rows, id)] = j < count ? stage[map[j]] : (T)0;
+            T *drow = dst + (size_t)id * cf;                 /* child_elem(j, cf, rows, id) = child_elem(j, cf, rows, 0) + id * cf */
+#pragma unroll
+            for (int u = 0; u < NS; ++u)
+                if ((int)threadIdx.x + u * kBlock < cslots) drow[to[u]] = from[u] >= 0 ? stage[from[u]] : (T)0;
             __syncthreads();
         }
         return;
