@@ -1552,7 +1552,10 @@ __global__ __launch_bounds__(kBlock) void compact_gather_kernel(const T *__restr
  * tiles into LDS with coalesced 16-byte loads, chunk by chunk, and picks the running frames' values from
  * there.  HBM traffic = one pass over the parent array (a third of a round) however many frames move. */
 constexpr int kGatherChunk = 4096;      /* elements staged at a time (16 KB of fp32) */
-constexpr int kGatherRowsPerBlock = 8;  /* rows a block walks */
+/* rows a block walks, the next one's loads in flight: 2-byte rows (8 KB for 4096 frames) left the memory pipe idle with one row
+ * per block (3.6 -> 4.9 TB/s with eight); 4-byte rows have enough in flight with one row per block and LOSE with eight (650 -> 880 us
+ * for the headline code's 3.7 GB: the block's serial stage / pick phases then stand in the way) */
+template <typename T> constexpr int gather_rows_per_block() { return sizeof(T) == 2 ? 8 : 1; }
 template <int V, typename T>
 __global__ __launch_bounds__(kBlock) void compact_gather_rows_kernel(const T *__restrict__ src, T *__restrict__ dst,
                                                                      const int32_t *__restrict__ map, int32_t count,
@@ -1566,8 +1569,9 @@ __global__ __launch_bounds__(kBlock) void compact_gather_rows_kernel(const T *__
     constexpr int NV = kGatherChunk / (kBlock * VEC);   /* 16-byte vectors a thread stages per chunk */
     __shared__ __attribute__((aligned(16))) T stage[kGatherChunk];
     const int cslots = ((count + cf - 1) / cf) * cf;    /* child slots in use (whole child tiles) */
-    const int64_t r0 = (int64_t)blockIdx.x * kGatherRowsPerBlock;
-    const int64_t r1 = r0 + kGatherRowsPerBlock < rows ? r0 + kGatherRowsPerBlock : rows;
+    constexpr int RPB = gather_rows_per_block<T>();
+    const int64_t r0 = (int64_t)blockIdx.x * RPB;
+    const int64_t r1 = r0 + RPB < rows ? r0 + RPB : rows;
     if (tiles <= TPC) {
         /* the usual case, a row's segments of all tiles fit one chunk: the block walks its rows with the NEXT row's
          * loads in flight while this row's values are picked from LDS (one row per block left the memory pipe idle

@@ -562,16 +562,16 @@ template <int V> int compact_and_finish(ldpc_decoder *d, int64_t frames, int cou
     const int ptiles = (int)((frames + 64 * V - 1) / (64 * V));
     if (d->msg_size == 2) {
         if (rowwise) {
-            compact_gather_rows_kernel<V, _Float16><<<(unsigned)((d->E + kGatherRowsPerBlock - 1) / kGatherRowsPerBlock), kBlock, 0, s>>>((const _Float16 *)d->Q.p, (_Float16 *)c->Q.p, d->cmap.p, count, d->E, ptiles, cf, d->qpos.p, c->qpos.p);
-            compact_gather_rows_kernel<V, _Float16><<<(unsigned)((d->N + kGatherRowsPerBlock - 1) / kGatherRowsPerBlock), kBlock, 0, s>>>((const _Float16 *)d->chan.p, (_Float16 *)c->chan.p, d->cmap.p, count, d->N, ptiles, cf);
+            compact_gather_rows_kernel<V, _Float16><<<(unsigned)((d->E + gather_rows_per_block<_Float16>() - 1) / gather_rows_per_block<_Float16>()), kBlock, 0, s>>>((const _Float16 *)d->Q.p, (_Float16 *)c->Q.p, d->cmap.p, count, d->E, ptiles, cf, d->qpos.p, c->qpos.p);
+            compact_gather_rows_kernel<V, _Float16><<<(unsigned)((d->N + gather_rows_per_block<_Float16>() - 1) / gather_rows_per_block<_Float16>()), kBlock, 0, s>>>((const _Float16 *)d->chan.p, (_Float16 *)c->chan.p, d->cmap.p, count, d->N, ptiles, cf);
         } else {
             compact_gather_kernel<V, _Float16><<<ge, kBlock, 0, s>>>((const _Float16 *)d->Q.p, (_Float16 *)c->Q.p, d->cmap.p, count, d->E, cf, d->qpos.p, c->qpos.p);
             compact_gather_kernel<V, _Float16><<<gn, kBlock, 0, s>>>((const _Float16 *)d->chan.p, (_Float16 *)c->chan.p, d->cmap.p, count, d->N, cf);
         }
     } else {
         if (rowwise) {
-            compact_gather_rows_kernel<V, float><<<(unsigned)((d->E + kGatherRowsPerBlock - 1) / kGatherRowsPerBlock), kBlock, 0, s>>>((const float *)d->Q.p, (float *)c->Q.p, d->cmap.p, count, d->E, ptiles, cf, d->qpos.p, c->qpos.p);
-            compact_gather_rows_kernel<V, float><<<(unsigned)((d->N + kGatherRowsPerBlock - 1) / kGatherRowsPerBlock), kBlock, 0, s>>>((const float *)d->chan.p, (float *)c->chan.p, d->cmap.p, count, d->N, ptiles, cf);
+            compact_gather_rows_kernel<V, float><<<(unsigned)((d->E + gather_rows_per_block<float>() - 1) / gather_rows_per_block<float>()), kBlock, 0, s>>>((const float *)d->Q.p, (float *)c->Q.p, d->cmap.p, count, d->E, ptiles, cf, d->qpos.p, c->qpos.p);
+            compact_gather_rows_kernel<V, float><<<(unsigned)((d->N + gather_rows_per_block<float>() - 1) / gather_rows_per_block<float>()), kBlock, 0, s>>>((const float *)d->chan.p, (float *)c->chan.p, d->cmap.p, count, d->N, ptiles, cf);
         } else {
             compact_gather_kernel<V, float><<<ge, kBlock, 0, s>>>((const float *)d->Q.p, (float *)c->Q.p, d->cmap.p, count, d->E, cf, d->qpos.p, c->qpos.p);
             compact_gather_kernel<V, float><<<gn, kBlock, 0, s>>>((const float *)d->chan.p, (float *)c->chan.p, d->cmap.p, count, d->N, cf);
