@@ -1678,11 +1678,19 @@ int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
 {
     const int64_t total = ldpc_out_bytes(d->cfg.K, frames, d->cfg.pack_mode);
     HIP_TRY(hipSetDevice(d->cfg.device));
-    const int64_t B = d->cfg.max_batch;
+    int64_t B = d->cfg.max_batch;
+    /* A large call that is ONE launch group is cut into two: the second half's channel values travel while the first
+     * half is decoded (one group exposes its whole copy: 21 ms of PCIe in front of a 94 ms decode for 4096 frames of the
+     * headline code; half batches decode at 0.99 of the full batch's rate).  Only where the grouping cannot be seen in
+     * the output: K a multiple of 8 (MyLdpc.cpp:577-616 starts every group at byte off*K/8). */
+    if (frames <= B && frames >= 2048 && d->cfg.K % 8 == 0 &&
+        (size_t)frames * d->N * sizeof(float) >= ((size_t)256 << 20))
+        B = ((frames + 1) / 2 + 255) / 256 * 256;
     if (d->cfg.pack_mode == LDPC_PACK_BITS && (d->cfg.K % 8) && frames > B)
         return fail(LDPC_ERR_UNSUPPORTED, "bit-packed output with K %% 8 != 0 cannot be chunked: "
                     "raise max_batch to cover all %lld frames", (long long)frames);
-    const int64_t stage_out = ldpc_out_bytes(d->cfg.K, B, d->cfg.pack_mode) + 8;
+    const int64_t Bmax = d->cfg.max_batch;      /* the slots hold a full group whatever this call's groups are */
+    const int64_t stage_out = ldpc_out_bytes(d->cfg.K, Bmax, d->cfg.pack_mode) + 8;
     /* more than one group: three staging slots, so that group k+1's channel values are copied in while
      * group k is decoded (the host may block in group k's early-termination polls) and group k-1's
      * results are copied out */
@@ -1691,11 +1699,11 @@ int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
     if (!d->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < nslots; ++i) {
         auto &sl = d->slot[i];
-        if (!sl.llr.p) HIP_TRY(sl.llr.alloc((size_t)B * d->N));
+        if (!sl.llr.p) HIP_TRY(sl.llr.alloc((size_t)Bmax * d->N));
         if (!sl.out.p) HIP_TRY(sl.out.alloc((size_t)stage_out));
-        if (!sl.iters.p) HIP_TRY(sl.iters.alloc((size_t)B));
+        if (!sl.iters.p) HIP_TRY(sl.iters.alloc((size_t)Bmax));
         if (!sl.h_out) HIP_TRY(hipHostMalloc((void **)&sl.h_out, (size_t)stage_out, hipHostMallocDefault));
-        if (!sl.h_iters) HIP_TRY(hipHostMalloc((void **)&sl.h_iters, (size_t)B * sizeof(int32_t), hipHostMallocDefault));
+        if (!sl.h_iters) HIP_TRY(hipHostMalloc((void **)&sl.h_iters, (size_t)Bmax * sizeof(int32_t), hipHostMallocDefault));
         if (!sl.h_head) HIP_TRY(hipHostMalloc((void **)&sl.h_head, kStageBytes, hipHostMallocDefault));
         if (!sl.h2d_done) HIP_TRY(hipEventCreateWithFlags(&sl.h2d_done, hipEventDisableTiming));
         if (!sl.all_done) HIP_TRY(hipEventCreateWithFlags(&sl.all_done, hipEventDisableTiming));

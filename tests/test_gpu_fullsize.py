@@ -497,3 +497,38 @@ def test_placement_search_keeps_results_and_reports_what_it_saw(built, code):
         assert np.array_equal(out, ref[0]) and np.array_equal(iters, ref[1]), place
         assert set(dec.array_addresses()) == {"Q", "R", "chan", "hard"}
         dec.close()
+
+
+def test_single_group_host_call_is_cut_in_two_and_gives_the_same_bytes(built, code):
+    """ldpc_decode cuts a large call that is ONE launch group (frames <= max_batch, >= 2048 frames, >= 256 MiB of channel
+    values, K a multiple of 8) into two groups so that the second half's copy runs beside the first half's decode.
+    Bytes and iteration counts must equal the device-buffer path, which decodes the batch as one group; 2100 frames:
+    groups of 1280 and 820, a ragged second one.  Both input modes; then the same handle with more frames than
+    max_batch (full-size groups again: the slots must still hold them)."""
+    import torch
+    rows, cols, g, og = code
+    frames = 2100
+    yd = channel.awgn_device(N, 0, frames, 0.66, seed=77)
+    nb = L.out_bytes(K, frames)
+    ref = L.Decoder(g, K, max_batch=4096, algo="ms", max_iter=25, poll_interval=2)
+    out_d = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    it_d = torch.empty(frames, dtype=torch.int32, device="cuda")
+    ref.decode_device(yd.data_ptr(), frames, out_d.data_ptr(), nb, it_d.data_ptr(), None)
+    torch.cuda.synchronize()
+    want_out, want_it = out_d.cpu().numpy(), it_d.cpu().numpy()
+    ref.close()
+    assert (want_it < 25).sum() > frames // 2            # a decoding operating point, not noise
+    yh = yd.cpu().numpy()
+    for mode in ("staged", "lock_pages"):
+        dec = L.Decoder(g, K, max_batch=4096, algo="ms", max_iter=25, poll_interval=2, host_input=mode)
+        out, iters = dec.decode(yh)
+        assert np.array_equal(out, want_out) and np.array_equal(iters, want_it), mode
+        dec.close()
+    small = L.Decoder(g, K, max_batch=2048, algo="ms", max_iter=25, poll_interval=2)
+    out, iters = small.decode(yh[:2048])                 # one group of exactly max_batch: cut into 1024 + 1024
+    kb = K // 8
+    assert np.array_equal(out, want_out[:2048 * kb]) and np.array_equal(iters, want_it[:2048])
+    out, iters = small.decode(yh)                        # 2100 > max_batch: groups of 2048 + 52
+    assert np.array_equal(out, want_out) and np.array_equal(iters, want_it)
+    small.close()
+    assert L.capi.host_locked_ranges() == (0, 0)
