@@ -176,8 +176,10 @@ enum ldpc_tune_field {
 #define LDPC_TUNE_ON(field) (1 << (field))
 #define LDPC_TUNE_OFF(field) (2 << (field))
 
+/* Counts (iterations, frames, converged frames, frame_rounds) cover the last call -- every launch group of an
+ * ldpc_decode() call; the times are those of its last launch group. */
 typedef struct ldpc_decode_stats {
-    int32_t iterations_launched; /* check/variable rounds enqueued by the last call          */
+    int32_t iterations_launched; /* check/variable rounds enqueued by the last call (maximum over its launch groups) */
     int32_t batch_time;          /* the reference's `Time=` (MyLdpc.cpp:838,1048): max iters  */
     int64_t frames;              /* frames of the last call                                  */
     int64_t frames_converged;    /* frames whose syndrome was clean                          */

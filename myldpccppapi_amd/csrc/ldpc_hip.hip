@@ -250,7 +250,13 @@ struct ldpc_decoder {
         hipEvent_t h2d_done = nullptr, all_done = nullptr;
         bool busy = false;
         int64_t off = 0, n = 0, dst = 0, copy_bytes = 0;
+        /* the group's counts for the call's statistics: the decoder's summary words (and those of the decoders its
+         * stragglers were handed to), copied out behind the group's decode, before the next group resets them */
+        int32_t *h_sum = nullptr;       /* pinned: [4][4] */
+        int g_iterations = 0, g_tiles = 0, g_children = 0, g_child_f[3] = {0, 0, 0};
     } slot[3];
+    /* counts of the last ldpc_decode() call over ALL its launch groups (ldpc_decoder_stats) */
+    struct CallCounts { bool valid = false; int32_t iterations = 0, batch_time = 0; int64_t frames = 0, converged = 0, frame_rounds = 0; } call;
     bool suppress_poll = false;
     int32_t *h_active = nullptr;        /* pinned */
     /* LDPC_HOST_INPUT_STAGED: a ring of pinned chunks the caller's channel values pass through, filled by
@@ -339,6 +345,7 @@ struct ldpc_decoder {
             if (sl.h_out) (void)hipHostFree(sl.h_out);
             if (sl.h_iters) (void)hipHostFree(sl.h_iters);
             if (sl.h_head) (void)hipHostFree(sl.h_head);
+            if (sl.h_sum) (void)hipHostFree(sl.h_sum);
             if (sl.h2d_done) (void)hipEventDestroy(sl.h2d_done);
             if (sl.all_done) (void)hipEventDestroy(sl.all_done);
         }
@@ -1545,6 +1552,7 @@ int ldpc_decode_device(ldpc_decoder *d, const float *llr_dev, int64_t frames, ui
     d->timing = d->timing_every > 0 && (d->timing_calls++ % d->timing_every) == 0;
     d->last_stream = s;
     d->last_frames = frames;
+    d->call.valid = false;          /* ldpc_decode() sets it again once all its groups are in */
     HIP_TRY(hipEventRecord(d->ev_begin, s));
     /* gaps between frames (K % 8 != 0, decodeCL.c:191-192 leaves them alone) read as 0 */
     if (out_dev) HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)std::min(out_bytes, need), s));
@@ -1705,6 +1713,7 @@ int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
         if (!sl.h_out) HIP_TRY(hipHostMalloc((void **)&sl.h_out, (size_t)stage_out, hipHostMallocDefault));
         if (!sl.h_iters) HIP_TRY(hipHostMalloc((void **)&sl.h_iters, (size_t)Bmax * sizeof(int32_t), hipHostMallocDefault));
         if (!sl.h_head) HIP_TRY(hipHostMalloc((void **)&sl.h_head, kStageBytes, hipHostMallocDefault));
+        if (!sl.h_sum) HIP_TRY(hipHostMalloc((void **)&sl.h_sum, 16 * sizeof(int32_t), hipHostMallocDefault));
         if (!sl.h2d_done) HIP_TRY(hipEventCreateWithFlags(&sl.h2d_done, hipEventDisableTiming));
         if (!sl.all_done) HIP_TRY(hipEventCreateWithFlags(&sl.all_done, hipEventDisableTiming));
     }
@@ -1714,12 +1723,23 @@ int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
     }
     ldpc::PageLockRegistry &registry = ldpc::PageLockRegistry::instance();
     /* a finished group's bytes go from the pinned slot to the caller's buffers */
+    ldpc_decoder::CallCounts counts;
+    const bool flooding_counts = !d->use_fused && d->cfg.algo != LDPC_ALGO_LAYERED && d->cfg.algo != LDPC_ALGO_LAYERED_HOST;
     auto drain = [&](ldpc_decoder::HostSlot &sl) -> int {
         if (!sl.busy) return LDPC_OK;
         sl.busy = false;
         HIP_TRY(hipEventSynchronize(sl.all_done));
         if (sl.copy_bytes > 0) memcpy(out_host + sl.dst, sl.h_out, (size_t)sl.copy_bytes);
         if (iters) memcpy(iters + sl.off, sl.h_iters, (size_t)sl.n * sizeof(int32_t));
+        /* the call's counts: sums over its groups, maxima for the iteration numbers (as ldpc_decoder_stats forms them) */
+        counts.frames += sl.n;
+        counts.converged += sl.h_sum[1];
+        counts.batch_time = std::max(counts.batch_time, sl.h_sum[0]);
+        counts.iterations = std::max(counts.iterations, sl.g_iterations);
+        if (flooding_counts) {
+            counts.frame_rounds += d->cfg.early_term ? (int64_t)sl.h_sum[2] * d->F : (int64_t)sl.g_iterations * sl.g_tiles * d->F;
+            for (int c = 0; c < sl.g_children; ++c) counts.frame_rounds += (int64_t)sl.h_sum[4 * (c + 1) + 2] * sl.g_child_f[c];
+        }
         return LDPC_OK;
     };
     int rc = LDPC_OK;
@@ -1824,6 +1844,13 @@ int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
             e = hipMemcpyAsync(sl.h_out, sl.out.p, (size_t)sl.copy_bytes, hipMemcpyDeviceToHost, d->stream);
         if (e == hipSuccess && iters)
             e = hipMemcpyAsync(sl.h_iters, sl.iters.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream);
+        sl.g_iterations = d->last_iterations; sl.g_tiles = d->last_tiles; sl.g_children = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(sl.h_sum, d->summary.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream);
+        for (const ldpc_decoder *p = d->handed_to; p && sl.g_children < 3 && e == hipSuccess; p = p->handed_to) {
+            sl.g_child_f[sl.g_children] = p->F;
+            e = hipMemcpyAsync(sl.h_sum + 4 * (sl.g_children + 1), p->summary.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream);
+            ++sl.g_children;
+        }
         if (e == hipSuccess) e = hipEventRecord(sl.all_done, d->stream);
         if (e != hipSuccess) { rc = fail(LDPC_ERR_HIP, "device-to-host staging: %s", hipGetErrorString(e)); break; }
         sl.busy = true;
@@ -1859,6 +1886,8 @@ int decode_host(ldpc_decoder *d, const float *llr_host, int64_t frames, uint8_t 
     }
     d->locked_blocks.clear();
     if (!first_error.empty()) g_err = first_error;
+    counts.valid = rc == LDPC_OK && ngroups > 1;       /* one group: the decoder's own record is the call's */
+    d->call = counts;
     return rc;
 }
 
@@ -1975,7 +2004,7 @@ int ldpc_decoder_stats(ldpc_decoder *d, ldpc_decode_stats *st)
     if (!d->have_last) return fail(LDPC_ERR_STATE, "no decode call to report on");
     if (!d->shards.empty()) {
         /* the devices ran side by side: counts add up, times and iteration numbers take the maximum.
-         * Each device reports its LAST launch group, as a single-device handle does. */
+         * Each device's counts cover all launch groups of its range, its times the last group. */
         for (ldpc_decoder *sh : d->shards) {
             if (!sh->have_last) continue;
             ldpc_decode_stats one;
@@ -2013,6 +2042,13 @@ int ldpc_decoder_stats(ldpc_decoder *d, ldpc_decode_stats *st)
             HIP_TRY(hipMemcpy(cs, p->summary.p, sizeof cs, hipMemcpyDeviceToHost));
             st->frame_rounds += (int64_t)cs[2] * p->F;
         }
+    }
+    if (d->call.valid) {            /* a host-buffer call of several launch groups: its counts cover all of them */
+        st->iterations_launched = d->call.iterations;
+        st->batch_time = d->call.batch_time;
+        st->frames = d->call.frames;
+        st->frames_converged = d->call.converged;
+        st->frame_rounds = d->call.frame_rounds;
     }
     for (size_t i = 0; i < d->spans_used; ++i) {
         float ms = 0;

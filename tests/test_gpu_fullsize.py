@@ -516,6 +516,7 @@ def test_single_group_host_call_is_cut_in_two_and_gives_the_same_bytes(built, co
     ref.decode_device(yd.data_ptr(), frames, out_d.data_ptr(), nb, it_d.data_ptr(), None)
     torch.cuda.synchronize()
     want_out, want_it = out_d.cpu().numpy(), it_d.cpu().numpy()
+    want_st = ref.stats()
     ref.close()
     assert (want_it < 25).sum() > frames // 2            # a decoding operating point, not noise
     yh = yd.cpu().numpy()
@@ -523,6 +524,10 @@ def test_single_group_host_call_is_cut_in_two_and_gives_the_same_bytes(built, co
         dec = L.Decoder(g, K, max_batch=4096, algo="ms", max_iter=25, poll_interval=2, host_input=mode)
         out, iters = dec.decode(yh)
         assert np.array_equal(out, want_out) and np.array_equal(iters, want_it), mode
+        st = dec.stats()                                 # the call's counts cover both groups
+        for k in ("frames", "frames_converged", "batch_time", "iterations_launched"):
+            assert st[k] == want_st[k], (mode, k, st[k], want_st[k])
+        assert 0 < st["frame_rounds"] <= want_st["frame_rounds"] * 1.2
         dec.close()
     small = L.Decoder(g, K, max_batch=2048, algo="ms", max_iter=25, poll_interval=2)
     out, iters = small.decode(yh[:2048])                 # one group of exactly max_batch: cut into 1024 + 1024
