@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "wimax_seeds.h"
 
@@ -148,15 +149,28 @@ int Coder::encode(char *srcCode, char *priorCode, int srcLength)
 {
     if (!isEncoder) return fail(LDPC_ERR_STATE, "encode: call forEncoder() first");
     if (!srcCode || !priorCode || srcLength <= 0) return fail(LDPC_ERR_ARG, "encode: bad arguments");
-    for (int offset = 0;; ++offset) {
-        const int at = (int)((long long)offset * ldpcK / 8);
-        if ((long long)(offset + 1) * ldpcK / 8 < srcLength) {           /* not the last, :557 */
-            encodeOnce(&srcCode[at], &priorCode[(long long)offset * ldpcN / 8], ldpcK / 8);
-        } else {                                                          /* the last, :561-565 */
-            encodeOnce(&srcCode[at], &priorCode[(long long)offset * ldpcN / 8], srcLength - at);
-            break;
-        }
+    /* frames [0, last]: frame `offset` starts at byte offset*K/8 and is the last one once (offset+1)*K/8 >= srcLength
+     * (:557-565).  The frames are independent and encodeOnce only reads the object: large payloads are spread over host
+     * threads, contiguous frame ranges each (4096 frames of the (64800, 32400) code: 41 ms on one core). */
+    long long last = 0;
+    while ((last + 1) * (long long)ldpcK / 8 < srcLength) ++last;
+    auto one = [&](long long offset) {
+        const int at = (int)(offset * ldpcK / 8);
+        encodeOnce(&srcCode[at], &priorCode[offset * ldpcN / 8], offset < last ? ldpcK / 8 : srcLength - at);
+    };
+    const long long frames = last + 1;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const long long threads = std::min<long long>(std::min<long long>(hw ? hw : 1, 16), frames * (long long)ldpcN / (1 << 21));
+    if (threads <= 1) {
+        for (long long offset = 0; offset < frames; ++offset) one(offset);
+        return LDPC_SUCCESS;
     }
+    std::vector<std::thread> pool;
+    for (long long t = 0; t < threads; ++t) {
+        const long long lo = frames * t / threads, hi = frames * (t + 1) / threads;
+        pool.emplace_back([&one, lo, hi] { for (long long offset = lo; offset < hi; ++offset) one(offset); });
+    }
+    for (auto &th : pool) th.join();
     return LDPC_SUCCESS;
 }
 

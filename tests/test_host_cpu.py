@@ -353,6 +353,11 @@ def test_cpp_coder_encoder_satisfies_h(built, tmp_path):
             out = subprocess.run([exe, str(rate), str(N), str(src), "4", "3", "ENC"],
                                  capture_output=True, text=True)
             assert out.returncode == 0 and "ParityFail=0" in out.stdout, (rate, N, out.stdout)
+    # a payload large enough for encode() to spread its frames over several host threads (>= 2 Mbit of code bits per
+    # thread): 8000 frames of (2304, 1152) and a short last one, and (648, 324) where frames start inside a byte
+    for rate, N, src in ((0, 2304, 8000 * 144 + 77), (0, 648, 20000 * 81 // 2 + 5)):
+        out = subprocess.run([exe, str(rate), str(N), str(src), "4", "3", "ENC"], capture_output=True, text=True)
+        assert out.returncode == 0 and "ParityFail=0" in out.stdout, (rate, N, out.stdout)
 
 
 def test_cpp_coder_encoder_equals_independent_gf2_solve(built, tmp_path):
