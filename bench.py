@@ -236,7 +236,7 @@ def coder_path(frames=BATCH_PER_GPU, iters=40, snr=2.6, repeat=3, timeout=600):
                     "ThroughPut = info bytes per wall-clock second of the best of %d decode() calls (the reference prints "
                     "CPU seconds, Test.cpp:111); at 2.6 dB the reference's fixed exp(8 y) sum-product leaves frames unconverged (ErrNum > 0, "
                     "Time = 40): the call does full work, as the headline step does; encode() is the structured O(E) encoder on "
-                    "z-bit words, single-threaded on the host"
+                    "z-bit words, the frames spread over the host's threads"
                     % (N_CODE, frames, frames, snr, iters, repeat)}
 
 
