@@ -1636,47 +1636,38 @@ __global__ __launch_bounds__(kBlock) void compact_gather_rows_kernel(const T *__
     }
 }
 
-/* hard bits: child bit of slot j <- parent bit of frame map[j] (gather), and back (scatter, one atomic per bit: few
- * frames).  One wave per column n and group g of 64 slots.  Gather with a child of cv frames per lane: the group's slots are
- * frames (g % cv) * 64 ... + 63 of child tile g / cv, i.e. the 64 / cv-bit field number g % cv of each of its cv mask
+/* hard bits, parent -> child (sum-product only: its decision rule can keep the previous bit): child bit of slot j <- parent
+ * bit of frame map[j].  One wave per column n and group g of 64 slots.  With a child of cv frames per lane the group's slots
+ * are frames (g % cv) * 64 ... + 63 of child tile g / cv, i.e. the 64 / cv-bit field number g % cv of each of its cv mask
  * words (bit l of word v = frame cv * l + v) -- written as that field alone, no atomics (compress_stride: the bits of the
- * lanes v, v + cv, ... of the ballot). */
-template <int V> __global__ __launch_bounds__(kBlock) void compact_hard_kernel(uint64_t *__restrict__ parent, uint64_t *__restrict__ child,
+ * lanes v, v + cv, ... of the ballot).  The way back is compact_hard_back_kernel. */
+template <int V> __global__ __launch_bounds__(kBlock) void compact_hard_kernel(const uint64_t *__restrict__ parent, uint64_t *__restrict__ child,
                                                                                const int32_t *__restrict__ map, int32_t count, int32_t N,
-                                                                               int scatter, int cv)
+                                                                               int cv)
 {
     constexpr int F = 64 * V;
-    const int cf = 64 * cv;
     const int j = threadIdx.x & 63, g = blockIdx.y, jg = g * 64 + j;
     const int64_t n = (int64_t)blockIdx.x * kWavesPerBlock + wave_id_in_block();
     if (n >= N) return;
     const int64_t f = jg < count ? map[jg] : 0;
     const int fi = (int)(f % F);
-    unsigned long long *word = reinterpret_cast<unsigned long long *>(parent) + ((f / F) * N + n) * V + fi % V;
-    const int l = fi / V;
-    if (!scatter) {
-        const bool bit = jg < count && ((*word >> l) & 1ull);
-        const uint64_t b = __ballot(bit);
-        uint64_t *cw = child + ((size_t)(g / cv) * N + n) * cv;              /* the cv words of child tile g / cv, column n */
-        if (cv == 1) {
-            if (j == 0) cw[0] = b;
-        } else if (cv == 2) {
-            if (j < 2) reinterpret_cast<uint32_t *>(cw + j)[g % 2] = (uint32_t)compress_stride<2>(b >> j);
-        } else {
-            if (j < 4) reinterpret_cast<uint16_t *>(cw + j)[g % 4] = (uint16_t)compress_stride<4>(b >> j);
-        }
-    } else if (jg < count) {
-        const int cfi = jg % cf;
-        const uint64_t cwv = child[((size_t)(jg / cf) * N + n) * cv + cfi % cv];
-        if ((cwv >> (cfi / cv)) & 1ull) atomicOr(word, 1ull << l);
-        else atomicAnd(word, ~(1ull << l));
+    const uint64_t word = parent[((f / F) * N + n) * V + fi % V];
+    const bool bit = jg < count && ((word >> (fi / V)) & 1ull);
+    const uint64_t b = __ballot(bit);
+    uint64_t *cw = child + ((size_t)(g / cv) * N + n) * cv;              /* the cv words of child tile g / cv, column n */
+    if (cv == 1) {
+        if (j == 0) cw[0] = b;
+    } else if (cv == 2) {
+        if (j < 2) reinterpret_cast<uint32_t *>(cw + j)[g % 2] = (uint32_t)compress_stride<2>(b >> j);
+    } else {
+        if (j < 4) reinterpret_cast<uint16_t *>(cw + j)[g % 4] = (uint16_t)compress_stride<4>(b >> j);
     }
 }
 
-/* The way back for many frames: one atomic per bit (above) is 44 M device atomics for 681 frames of the
- * rate-9/10 code.  Instead every parent word is rewritten by ONE thread that looks up, for the bits of its
- * frames that were handed over, the child's bit: inv[frame] = child slot, moved[(tile, v)] = which bits of
- * that word moved (both filled by compact_inverse_kernel). */
+/* The way back (for any number of frames; one atomic per bit, as rounds 2 and early 3 did it, is 44 M device
+ * atomics for 681 frames of the rate-9/10 code): every parent word is rewritten by ONE thread that looks up, for
+ * the bits of its frames that were handed over, the child's bit: inv[frame] = where that bit sits in the child,
+ * moved[(tile, v)] = which bits of that word moved (both filled by compact_inverse_kernel). */
 template <int V> __global__ void compact_inverse_kernel(const int32_t *__restrict__ map, int32_t count, int32_t *__restrict__ inv,
                                                         unsigned long long *__restrict__ moved, int cv)
 {

@@ -587,7 +587,7 @@ template <int V> int compact_and_finish(ldpc_decoder *d, int64_t frames, int cou
     /* the hard bits travel only where the next decision can depend on the previous one: the sum-product rule keeps the old
      * bit on a tie or a NaN (decodeCL.c:78-82); min-sum decides every bit anew in every round (bit = !(p > 0), :161-165) */
     HIP_TRY(hipMemsetAsync(c->hard.p, 0, (size_t)ct * d->N * cv * sizeof(uint64_t), s));
-    if (d->cfg.algo == LDPC_ALGO_SP) compact_hard_kernel<V><<<gn, kBlock, 0, s>>>(d->hard.p, c->hard.p, d->cmap.p, count, d->N, 0, cv);
+    if (d->cfg.algo == LDPC_ALGO_SP) compact_hard_kernel<V><<<gn, kBlock, 0, s>>>(d->hard.p, c->hard.p, d->cmap.p, count, d->N, cv);
     compact_child_state_kernel<0><<<ct, 64, 0, s>>>(c->done.p, c->iters.p, count, d->cfg.max_iter, cv);
     HIP_TRY(hipGetLastError());
     c->timing = false;
