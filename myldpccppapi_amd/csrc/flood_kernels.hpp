@@ -1664,6 +1664,45 @@ template <int V> __global__ __launch_bounds__(kBlock) void compact_hard_kernel(c
     }
 }
 
+/* The same gather for parents of up to kGatherParentWords mask words per column (4096 frames at V = 4) and up to
+ * 2 * kCompactCapacity slots: a block takes 64 columns, stages their parent words (contiguous per tile) and the decoded slot
+ * table in LDS, and each thread assembles whole child words from there.  One wave per column and 64 slots (above) reads one
+ * scattered 8-byte word per lane through the L2: 66 M requests, 150-200 us for the 1024-frame child of the headline code. */
+constexpr int kGatherParentWords = 64;
+template <int V> __global__ __launch_bounds__(kBlock) void compact_hard_lds_kernel(const uint64_t *__restrict__ parent, uint64_t *__restrict__ child,
+                                                                                   const int32_t *__restrict__ map, int32_t count, int32_t N,
+                                                                                   int cv, int ptiles, int cwords)
+{
+    constexpr int F = 64 * V;
+    constexpr int COLS = 64, TPC = kBlock / COLS;           /* columns per block, threads per column (one wave each) */
+    __shared__ uint64_t pw[kGatherParentWords][COLS];
+    __shared__ int32_t sbit[2 * kCompactCapacity];          /* slot j -> (parent word of the column) << 8 | bit */
+    const int n0 = blockIdx.x * COLS;
+    for (int idx = threadIdx.x; idx < ptiles * COLS * V; idx += kBlock) {
+        const int tile = idx / (COLS * V), rem = idx % (COLS * V), c = rem / V, v = rem % V;
+        pw[tile * V + v][c] = n0 + c < N ? parent[((size_t)tile * N + n0) * V + rem] : 0ull;
+    }
+    for (int j = threadIdx.x; j < count; j += kBlock) {
+        const int f = map[j], fi = f % F;
+        sbit[j] = (((f / F) * V + fi % V) << 8) | (fi / V);
+    }
+    __syncthreads();
+    const int c = threadIdx.x % COLS, q = threadIdx.x / COLS, n = n0 + c;
+    if (n >= N) return;
+    const int cf = 64 * cv;
+    for (int cwd = q; cwd < cwords; cwd += TPC) {
+        const int ctile = cwd / cv, cword = cwd % cv;       /* per child word, not per bit */
+        uint64_t val = 0;
+        for (int b = 0; b < 64; ++b) {
+            const int j = ctile * cf + b * cv + cword;      /* the slot whose bit is bit b of this word */
+            if (j >= count) break;
+            const int sb = sbit[j];
+            val |= ((pw[sb >> 8][c] >> (sb & 255)) & 1ull) << b;
+        }
+        child[((size_t)ctile * N + n) * cv + cword] = val;
+    }
+}
+
 /* The way back (for any number of frames; one atomic per bit, as rounds 2 and early 3 did it, is 44 M device
  * atomics for 681 frames of the rate-9/10 code): every parent word is rewritten by ONE thread that looks up, for
  * the bits of its frames that were handed over, the child's bit: inv[frame] = where that bit sits in the child,

@@ -587,7 +587,12 @@ template <int V> int compact_and_finish(ldpc_decoder *d, int64_t frames, int cou
     /* the hard bits travel only where the next decision can depend on the previous one: the sum-product rule keeps the old
      * bit on a tie or a NaN (decodeCL.c:78-82); min-sum decides every bit anew in every round (bit = !(p > 0), :161-165) */
     HIP_TRY(hipMemsetAsync(c->hard.p, 0, (size_t)ct * d->N * cv * sizeof(uint64_t), s));
-    if (d->cfg.algo == LDPC_ALGO_SP) compact_hard_kernel<V><<<gn, kBlock, 0, s>>>(d->hard.p, c->hard.p, d->cmap.p, count, d->N, cv);
+    if (d->cfg.algo == LDPC_ALGO_SP) {
+        if (ptiles * V <= kGatherParentWords && count <= 2 * kCompactCapacity)
+            compact_hard_lds_kernel<V><<<(unsigned)((d->N + 63) / 64), kBlock, 0, s>>>(d->hard.p, c->hard.p, d->cmap.p, count, d->N, cv, ptiles, (int)cg);
+        else
+            compact_hard_kernel<V><<<gn, kBlock, 0, s>>>(d->hard.p, c->hard.p, d->cmap.p, count, d->N, cv);
+    }
     compact_child_state_kernel<0><<<ct, 64, 0, s>>>(c->done.p, c->iters.p, count, d->cfg.max_iter, cv);
     HIP_TRY(hipGetLastError());
     c->timing = false;
