@@ -3,7 +3,7 @@
 imports oracle/).  Random base matrices (circulant size, layers, row weights 1..24, single-layer
 columns anywhere), random noise levels, a few zeros / huge values / NaNs in the channel values;
 layered, min-sum and fused-flooding min-sum, each on the record kernels (default), on the
-LDS-resident kernels and on the streaming kernels.  usage: gpu_soak.py [cases] [seed]"""
+LDS-resident kernels and on the streaming kernels.  usage: python tests/soak_gpu.py [cases] [seed]  (a script, not collected by pytest)"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
