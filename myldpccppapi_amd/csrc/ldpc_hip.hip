@@ -1080,7 +1080,7 @@ template <int V> int time_check_phase(ldpc_decoder *d, float *ms_out)
  * large does not take its first allocations as they come: holding what it has, it tries up to `tune_place`
  * (default 6) fresh allocations for R, then for Q, times one message round (check + variable-node phase) with each,
  * keeps the fastest and
- * releases the rest at the end; a stage stops as soon as it has seen the fast speed next to the slow one (a
+ * releases the rest at the end; after at least four measurements a stage stops as soon as it has seen the fast speed next to the slow one (a
  * candidate at least 9 % faster than another).  No guarantee: in some processes every pair is slow.  About 10 ms and 4 GB per candidate while the decoder is being created. */
 template <int V> int placement_search(ldpc_decoder *d, size_t TF)
 {
@@ -1099,8 +1099,10 @@ template <int V> int placement_search(ldpc_decoder *d, size_t TF)
         DevBuf<uint8_t> &arr = stage == 0 ? d->R : d->Q;
         for (int c = 1; c < want; ++c) {
             /* three speeds of the check phase occur (about 1 : 0.88 : 0.83, i.e. 1 : 0.93 : 0.895 for the whole round):
-             * stop once the fastest of them has been seen next to the slowest */
-            if (lo < 0.91f * hi && best_ms <= lo) break;
+             * stop once the fastest of them has been seen next to the slowest -- but not before four measurements: the
+             * speeds within the fast class still differ by 2-3 % (14 processes: a search that stopped after 2.63, 2.61,
+             * 2.36 ms kept 2.36 where its neighbours found 2.28-2.31) */
+            if (lo < 0.91f * hi && best_ms <= lo && d->place_candidates >= 4) break;
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * bq + ((size_t)2 << 30)) break;
             /* Device memory comes in two classes that alternate every 16 GiB of (physical) address space, and a read
