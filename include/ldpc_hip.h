@@ -134,7 +134,7 @@ typedef struct ldpc_decoder_config {
                                    lie behind these two arrays decides between speeds of the streaming check kernel that
                                    differ by up to 19 % and last as long as the allocations.
                                    0 = automatic (up to 6 per array when the arrays hold at least 256 MiB and memory
-                                   allows; a stage stops once it has seen the fast speed next to the slow one), 1 = take the first allocations
+                                   allows; after four measurements a stage stops once it has seen the fast speed next to the slow one), 1 = take the first allocations
                                    as they come, 2..8 = that many per array                              */
     int32_t host_input;         /* enum ldpc_host_input: how ldpc_decode() moves the caller's pageable channel
                                    values to the device (memory the caller has page-locked itself is always
